@@ -1,0 +1,177 @@
+/*
+ * pqd.h -- C ABI of the MI355X (gfx950) Parquet page-value decode library.
+ *
+ * This is the boundary a Go shim binds with cgo to stand behind parquet-go's
+ * codec interface: plain pointers and sizes, no C++ or torch types.  Each
+ * entry point names the reference interface it replaces (paths relative to
+ * the parquet-go source tree).
+ *
+ * Two levels:
+ *   1. a batched, device-resident interface (pqd_batch_*): many pages per
+ *      launch, all pointers are device pointers, nothing is copied or
+ *      allocated between create and finish.  This is the measured path.
+ *   2. per-method host wrappers (pqd_decode_*): host pointers in, host
+ *      pointers out, one call per reference Decode method; they stage through
+ *      device memory and run the same kernels.
+ *
+ * Every decode kernel is hand-written HIP for gfx950; there is no CPU
+ * fallback: without a usable GPU every call returns PQD_ERR_DEVICE.
+ */
+#ifndef PQD_H
+#define PQD_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "pqd_status.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PQD_ABI_VERSION 1
+
+typedef struct pqd_ctx pqd_ctx;     /* one per process and device */
+typedef struct pqd_batch pqd_batch; /* a prepared set of pages */
+typedef struct pqd_dict pqd_dict;   /* a device-resident dictionary */
+
+/* ---- context ----------------------------------------------------------- */
+
+int pqd_abi_version(void);
+const char* pqd_status_name(int status);
+
+/* Binds the library to a HIP device.  Safe to call from several threads;
+ * contexts are independent ("Encoding instances must be safe to use
+ * concurrently", encoding/encoding.go:19). */
+int pqd_ctx_create(int device, pqd_ctx** out);
+void pqd_ctx_destroy(pqd_ctx* ctx);
+
+/* ---- batched, device-resident decode ------------------------------------ */
+
+/*
+ * One page of one column chunk: the unit Column.decodeDataPage hands to
+ * Type.Decode (column.go:845-911, :881), Column.decodeLevels hands to
+ * Encoding.DecodeLevels (column.go:931-948) or Column.decodeDictionary hands
+ * to the PLAIN decoder (column.go:963-993).
+ *
+ * `encoding` is the format.Encoding code, `kind` selects which Decode method
+ * of encoding.Encoding the item stands for (encoding/encoding.go:48-56).
+ * `bit_width` is Encoding.BitWidth for RLE / BIT_PACKED
+ * (encoding/rle/rle.go:30-33, encoding/bitpacked/bitpacked.go:8-11) and the
+ * type length for FIXED_LEN_BYTE_ARRAY.
+ *
+ * With a non-null `dict` an RLE_DICTIONARY / PLAIN_DICTIONARY page is decoded
+ * straight to values: index unpack, the newIndexedPage length fix-up
+ * (dictionary.go:136-162: cut to num_values or zero-extend) and
+ * Dictionary.Lookup (dictionary.go:64-69, dictionary_amd64.go:36-58) fused in
+ * one kernel; `kind` then names the value type (INT32/INT64/FLOAT/DOUBLE/INT96)
+ * and `dst_stride` the distance between rows in bytes (0 = dense;
+ * sparse.Array's stride, sparse/array.go:33-37).
+ *
+ * `num_values` >= 0 cuts the output to that many values the way the callers
+ * do (column.go:940-945, dictionary.go:136-162); -1 returns everything the
+ * stream holds, as the Decode methods themselves do.
+ */
+typedef struct pqd_page {
+    const void* src;      /* encoded page bytes */
+    uint64_t    src_len;
+    void*       dst;      /* decoded values */
+    uint64_t    dst_cap;  /* bytes */
+    uint32_t*   offsets;  /* BYTE_ARRAY: n+1 value offsets */
+    uint64_t    offsets_cap; /* entries */
+    const void* dict;     /* optional dictionary values (device) */
+    uint64_t    dict_len; /* entries */
+    int64_t     num_values;
+    int32_t     encoding; /* pqd_encoding */
+    int32_t     kind;     /* pqd_kind */
+    int32_t     bit_width;
+    int32_t     dst_stride;
+    /* results, filled by pqd_batch_finish */
+    int32_t     status;      /* pqd_status */
+    int32_t     reserved;
+    int64_t     status_arg;
+    uint64_t    out_values;  /* values decoded (offsets written - 1 for BYTE_ARRAY) */
+    uint64_t    out_bytes;   /* bytes written to dst */
+    uint64_t    consumed;    /* source bytes consumed (DELTA streams) */
+} pqd_page;
+
+/* Validates the items, groups them by kernel family, uploads the descriptors
+ * and reserves scratch (run tables, length buffers).  All device pointers
+ * must stay valid until the batch is destroyed. */
+int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_batch** out);
+
+/* Enqueues every kernel of the batch on `hip_stream` (a hipStream_t, NULL =
+ * the default stream).  Does not allocate, copy or synchronise; may be called
+ * any number of times. */
+int pqd_batch_launch(pqd_batch* batch, void* hip_stream);
+
+/* Waits for the stream and writes the result fields of pages[0..n). */
+int pqd_batch_finish(pqd_batch* batch, void* hip_stream, pqd_page* pages, uint64_t n_pages);
+
+void pqd_batch_destroy(pqd_batch* batch);
+
+/* create + launch + finish + destroy. */
+int pqd_decode_batch(pqd_ctx* ctx, pqd_page* pages, uint64_t n_pages, void* hip_stream);
+
+/* ---- per-method host wrappers (the cgo surface) ---------------------------- */
+
+/*
+ * Each wrapper replaces one Decode method of encoding.Encoding
+ * (encoding/encoding.go:48-56) for the encoding code given: host src, host
+ * dst of dst_cap bytes; *out_bytes bytes were produced.  On
+ * PQD_ERR_DST_TOO_SMALL *status_arg holds the capacity to retry with, which is
+ * how the shim renders Go's "may grow dst" contract (encoding/rle/rle.go:510-522).
+ */
+int pqd_decode_levels(pqd_ctx* ctx, int encoding, int bit_width, const uint8_t* src, uint64_t src_len,
+                      uint8_t* dst, uint64_t dst_cap, uint64_t* out_bytes, int64_t* status_arg);
+int pqd_decode_boolean(pqd_ctx* ctx, int encoding, const uint8_t* src, uint64_t src_len,
+                       uint8_t* dst, uint64_t dst_cap, uint64_t* out_bytes, int64_t* status_arg);
+int pqd_decode_int32(pqd_ctx* ctx, int encoding, int bit_width, const uint8_t* src, uint64_t src_len,
+                     int32_t* dst, uint64_t dst_cap, uint64_t* out_bytes, int64_t* status_arg);
+int pqd_decode_int64(pqd_ctx* ctx, int encoding, const uint8_t* src, uint64_t src_len,
+                     int64_t* dst, uint64_t dst_cap, uint64_t* out_bytes, int64_t* status_arg);
+int pqd_decode_int96(pqd_ctx* ctx, int encoding, const uint8_t* src, uint64_t src_len,
+                     uint8_t* dst, uint64_t dst_cap, uint64_t* out_bytes, int64_t* status_arg);
+int pqd_decode_float(pqd_ctx* ctx, int encoding, const uint8_t* src, uint64_t src_len,
+                     float* dst, uint64_t dst_cap, uint64_t* out_bytes, int64_t* status_arg);
+int pqd_decode_double(pqd_ctx* ctx, int encoding, const uint8_t* src, uint64_t src_len,
+                      double* dst, uint64_t dst_cap, uint64_t* out_bytes, int64_t* status_arg);
+int pqd_decode_byte_array(pqd_ctx* ctx, int encoding, const uint8_t* src, uint64_t src_len,
+                          uint8_t* dst, uint64_t dst_cap, uint32_t* offsets, uint64_t offsets_cap,
+                          uint64_t* out_bytes, uint64_t* out_offsets, int64_t* status_arg);
+int pqd_decode_fixed_len_byte_array(pqd_ctx* ctx, int encoding, int size, const uint8_t* src, uint64_t src_len,
+                                    uint8_t* dst, uint64_t dst_cap, uint64_t* out_bytes, int64_t* status_arg);
+
+/* Encoding.EstimateDecodeByteArraySize (encoding/encoding.go:58-67;
+ * encoding/delta/length_byte_array.go:65-70, byte_array.go:176-183,
+ * encoding/plain/plain.go:106-108). Never fails: 0 on any error. */
+int64_t pqd_estimate_decode_byte_array_size(pqd_ctx* ctx, int encoding, const uint8_t* src, uint64_t src_len);
+
+/* Encoding.CanDecodeInPlace (encoding/encoding.go:69-71): PLAIN and
+ * DELTA_LENGTH_BYTE_ARRAY (plain.go:110-112, length_byte_array.go:72-74). */
+int pqd_can_decode_in_place(int encoding);
+
+/* ---- dictionary surface ---------------------------------------------------- */
+
+/* A dictionary of `n` fixed-width values (width 4, 8 or 12 bytes) copied to
+ * the device: what Type.NewDictionary keeps after decodeDictionary
+ * (column.go:992, dictionary_int64.go:18-26). */
+int pqd_dict_create(pqd_ctx* ctx, const void* values, uint64_t n, uint32_t width, pqd_dict** out);
+void pqd_dict_destroy(pqd_dict* dict);
+
+/* Dictionary.Lookup (dictionary.go:64-69; dictionaryLookup32/64,
+ * dictionary_amd64.go:30-46, dictionary_amd64.s:578-711):
+ * rows[i*stride .. +width) = dict[indexes[i]], host pointers.  An index outside
+ * [0, n) yields PQD_ERR_INDEX_OUT_OF_BOUNDS (the reference panics). */
+int pqd_dict_lookup(pqd_dict* dict, const int32_t* indexes, uint64_t n, void* rows, uint64_t stride,
+                    int64_t* status_arg);
+
+/* The same on device pointers, enqueued on `hip_stream`; `status_dev` points to
+ * two int64 in device memory: {status, arg}, written by the kernel. */
+int pqd_dict_lookup_device(pqd_ctx* ctx, const void* dict_dev, uint64_t dict_len, uint32_t width,
+                           const int32_t* indexes_dev, uint64_t n, void* rows_dev, uint64_t stride,
+                           int64_t* status_dev, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PQD_H */

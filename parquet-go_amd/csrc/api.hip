@@ -1,0 +1,344 @@
+// api.hip -- host side of the C ABI declared in include/pqd.h: contexts,
+// batches (classification of pages into kernel families, descriptor upload,
+// scratch carving, launch order) and the per-method host-pointer wrappers.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "pqd_internal.h"
+
+using namespace pqd;
+
+namespace {
+
+// One user page maps to `primary` (the item whose result is reported) plus,
+// for the DELTA byte-array encodings, the length-stream items before it.
+struct PageMap {
+    int32_t primary;    // item index, or -1 when rejected on the host
+    int32_t host_status;
+    int64_t host_arg;
+};
+
+struct FamilyList {
+    std::vector<uint32_t> items; // item indexes
+    uint32_t* dev = nullptr;
+};
+
+} // namespace
+
+struct pqd_batch {
+    pqd_ctx* ctx = nullptr;
+    uint64_t n_pages = 0;
+    std::vector<PageMap> map;
+    std::vector<DevPage> items;
+    void* arena = nullptr;
+    size_t arena_bytes = 0;
+    DevPage* d_items = nullptr;
+    DevResult* d_results = nullptr;
+    FamilyList fam[16];
+    // RLE expand grid
+    uint64_t* d_rle_tile_prefix = nullptr;
+    uint64_t rle_tiles = 0;
+    // generic tile grids for the element-parallel families
+    uint64_t* d_tile_prefix[16] = {nullptr};
+    uint64_t tiles[16] = {0};
+    std::vector<DevResult> h_results;
+};
+
+namespace {
+
+inline bool hip_ok(hipError_t e) { return e == hipSuccess; }
+
+#define PQD_HIP(call)                                   \
+    do {                                                \
+        hipError_t e_ = (call);                         \
+        if (e_ != hipSuccess) return PQD_ERR_DEVICE;    \
+    } while (0)
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+int32_t elem_width_of(int32_t kind, int32_t bit_width) {
+    switch (kind) {
+        case PQD_KIND_LEVELS: return 1;
+        case PQD_KIND_BOOLEAN: return 1;
+        case PQD_KIND_INT32: return 4;
+        case PQD_KIND_INT64: return 8;
+        case PQD_KIND_INT96: return 12;
+        case PQD_KIND_FLOAT: return 4;
+        case PQD_KIND_DOUBLE: return 8;
+        case PQD_KIND_BYTE_ARRAY: return 1;
+        case PQD_KIND_FIXED_LEN_BYTE_ARRAY: return bit_width;
+        default: return 0;
+    }
+}
+
+// Which kernel family decodes (encoding, kind); FAM_NONE = not supported, as
+// encoding.NotSupported would answer (encoding/notsupported.go:163-197).
+int32_t classify(const pqd_page& p) {
+    const int32_t e = p.encoding, k = p.kind;
+    switch (e) {
+        case PQD_ENC_DELTA_BINARY_PACKED:
+            if (k == PQD_KIND_INT32) return FAM_DELTA32;
+            if (k == PQD_KIND_INT64) return FAM_DELTA64;
+            return FAM_NONE;
+        case PQD_ENC_RLE:
+            if (k == PQD_KIND_LEVELS || k == PQD_KIND_INT32 || k == PQD_KIND_BOOLEAN) return FAM_RLE;
+            return FAM_NONE;
+        case PQD_ENC_RLE_DICTIONARY:
+        case PQD_ENC_PLAIN_DICTIONARY:
+            if (p.dict != nullptr || p.dict_len > 0) {
+                if (k == PQD_KIND_INT32 || k == PQD_KIND_INT64 || k == PQD_KIND_FLOAT || k == PQD_KIND_DOUBLE ||
+                    k == PQD_KIND_INT96)
+                    return FAM_RLE;
+                return FAM_NONE;
+            }
+            if (k == PQD_KIND_INT32) return FAM_RLE;
+            return FAM_NONE;
+        case PQD_ENC_BIT_PACKED:
+            return k == PQD_KIND_LEVELS ? FAM_BITPACKED : FAM_NONE;
+        case PQD_ENC_BYTE_STREAM_SPLIT:
+            if (k == PQD_KIND_INT32 || k == PQD_KIND_INT64 || k == PQD_KIND_FLOAT || k == PQD_KIND_DOUBLE ||
+                k == PQD_KIND_FIXED_LEN_BYTE_ARRAY)
+                return FAM_BSS;
+            return FAM_NONE;
+        case PQD_ENC_PLAIN:
+            if (k == PQD_KIND_BYTE_ARRAY) return FAM_PLAIN_BYTE_ARRAY;
+            if (k == PQD_KIND_LEVELS) return FAM_NONE;
+            return FAM_PLAIN_FIXED;
+        case PQD_ENC_DELTA_LENGTH_BYTE_ARRAY:
+            return k == PQD_KIND_BYTE_ARRAY ? FAM_DLBA : FAM_NONE;
+        case PQD_ENC_DELTA_BYTE_ARRAY:
+            return (k == PQD_KIND_BYTE_ARRAY || k == PQD_KIND_FIXED_LEN_BYTE_ARRAY) ? FAM_DBA : FAM_NONE;
+        default:
+            return FAM_NONE;
+    }
+}
+
+DevPage make_item(const pqd_page& p, int32_t family) {
+    DevPage d;
+    std::memset(&d, 0, sizeof d);
+    d.src = static_cast<const uint8_t*>(p.src);
+    d.src_len = p.src_len;
+    d.dst = static_cast<uint8_t*>(p.dst);
+    d.dst_cap = p.dst_cap;
+    d.offsets = p.offsets;
+    d.offsets_cap = p.offsets_cap;
+    d.dict = static_cast<const uint8_t*>(p.dict);
+    d.dict_len = p.dict_len;
+    d.num_values = p.num_values;
+    d.encoding = p.encoding;
+    d.kind = p.kind;
+    d.bit_width = p.bit_width;
+    d.dst_stride = p.dst_stride;
+    d.elem_width = elem_width_of(p.kind, p.bit_width);
+    d.family = family;
+    d.chain = -1;
+    d.fused = 0;
+    return d;
+}
+
+} // namespace
+
+extern "C" {
+
+int pqd_abi_version(void) { return PQD_ABI_VERSION; }
+
+const char* pqd_status_name(int status) {
+    switch (status) {
+        case PQD_OK: return "OK";
+        case PQD_ERR_NOT_SUPPORTED: return "NOT_SUPPORTED";
+        case PQD_ERR_INVALID_ARGUMENT: return "INVALID_ARGUMENT";
+        case PQD_ERR_INVALID_BIT_WIDTH: return "INVALID_BIT_WIDTH";
+        case PQD_ERR_UNEXPECTED_EOF: return "UNEXPECTED_EOF";
+        case PQD_ERR_VARINT_OVERFLOW: return "VARINT_OVERFLOW";
+        case PQD_ERR_RUN_TOO_LARGE: return "RUN_TOO_LARGE";
+        case PQD_ERR_BAD_DELTA_HEADER: return "BAD_DELTA_HEADER";
+        case PQD_ERR_FIRST_VALUE_RANGE: return "FIRST_VALUE_RANGE";
+        case PQD_ERR_MISSING_VALUES: return "MISSING_VALUES";
+        case PQD_ERR_NEGATIVE_LENGTH: return "NEGATIVE_LENGTH";
+        case PQD_ERR_LENGTH_OUT_OF_BOUNDS: return "LENGTH_OUT_OF_BOUNDS";
+        case PQD_ERR_PREFIX_SUFFIX_MISMATCH: return "PREFIX_SUFFIX_MISMATCH";
+        case PQD_ERR_NEGATIVE_PREFIX: return "NEGATIVE_PREFIX";
+        case PQD_ERR_PREFIX_OUT_OF_BOUNDS: return "PREFIX_OUT_OF_BOUNDS";
+        case PQD_ERR_INDEX_OUT_OF_BOUNDS: return "INDEX_OUT_OF_BOUNDS";
+        case PQD_ERR_DST_TOO_SMALL: return "DST_TOO_SMALL";
+        case PQD_ERR_DEVICE: return "DEVICE";
+        case PQD_ERR_OFFSETS_TOO_SMALL: return "OFFSETS_TOO_SMALL";
+        default: return "UNKNOWN";
+    }
+}
+
+int pqd_ctx_create(int device, pqd_ctx** out) {
+    if (out == nullptr) return PQD_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return PQD_ERR_DEVICE;
+    PQD_HIP(hipSetDevice(device));
+    pqd_ctx* ctx = new (std::nothrow) pqd_ctx;
+    if (ctx == nullptr) return PQD_ERR_DEVICE;
+    ctx->device = device;
+    *out = ctx;
+    return PQD_OK;
+}
+
+void pqd_ctx_destroy(pqd_ctx* ctx) { delete ctx; }
+
+int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_batch** out) {
+    if (ctx == nullptr || out == nullptr || (pages == nullptr && n_pages > 0)) return PQD_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    PQD_HIP(hipSetDevice(ctx->device));
+    pqd_batch* b = new (std::nothrow) pqd_batch;
+    if (b == nullptr) return PQD_ERR_DEVICE;
+    b->ctx = ctx;
+    b->n_pages = n_pages;
+    b->map.resize(n_pages);
+
+    // ---- classify ----
+    size_t runs_entries = 0;
+    for (uint64_t i = 0; i < n_pages; i++) {
+        const pqd_page& p = pages[i];
+        PageMap m = {-1, PQD_OK, 0};
+        int32_t family = classify(p);
+        if (family == FAM_NONE) {
+            m.host_status = PQD_ERR_NOT_SUPPORTED;
+        } else if ((p.src == nullptr && p.src_len > 0) || (p.dst == nullptr && p.dst_cap > 0)) {
+            m.host_status = PQD_ERR_INVALID_ARGUMENT;
+        } else if (family == FAM_DELTA32 || family == FAM_DELTA64) {
+            m.primary = (int32_t)b->items.size();
+            b->items.push_back(make_item(p, family));
+        } else if (family == FAM_RLE) {
+            DevPage d = make_item(p, family);
+            const bool dict_enc = p.encoding == PQD_ENC_RLE_DICTIONARY || p.encoding == PQD_ENC_PLAIN_DICTIONARY;
+            d.fused = (dict_enc && (p.dict != nullptr || p.dict_len > 0)) ? 1 : 0;
+            if (!d.fused && dict_enc) d.elem_width = 4;
+            d.runs_cap = p.src_len + 1;
+            runs_entries += d.runs_cap;
+            m.primary = (int32_t)b->items.size();
+            b->items.push_back(d);
+        } else {
+            m.host_status = PQD_ERR_NOT_SUPPORTED; // family not wired up yet
+        }
+        b->map[i] = m;
+    }
+
+    // ---- family lists and the RLE tile grid ----
+    std::vector<uint64_t> rle_prefix;
+    for (uint32_t k = 0; k < b->items.size(); k++) {
+        DevPage& d = b->items[k];
+        b->fam[d.family].items.push_back(k);
+        if (d.family == FAM_RLE) {
+            const uint64_t stride = d.dst_stride > 0 ? (uint64_t)d.dst_stride : (uint64_t)d.elem_width;
+            uint64_t bound = stride ? d.dst_cap / stride + 1 : 0;
+            if (d.num_values >= 0 && (uint64_t)d.num_values < bound) bound = (uint64_t)d.num_values;
+            uint64_t tiles = std::max<uint64_t>(1, (bound + RLE_TILE - 1) / RLE_TILE);
+            rle_prefix.push_back(b->rle_tiles);
+            d.tile_base = b->rle_tiles;
+            b->rle_tiles += tiles;
+        }
+    }
+    rle_prefix.push_back(b->rle_tiles);
+    if (b->rle_tiles > 0x7fffffffull) { delete b; return PQD_ERR_INVALID_ARGUMENT; }
+
+    // ---- carve one arena ----
+    const size_t n_items = b->items.size();
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_items = carve(n_items * sizeof(DevPage));
+    const size_t o_results = carve(n_items * sizeof(DevResult));
+    size_t o_fam[16];
+    for (int f = 0; f < 16; f++) o_fam[f] = carve(b->fam[f].items.size() * sizeof(uint32_t));
+    const size_t o_rle_prefix = carve(rle_prefix.size() * sizeof(uint64_t));
+    const size_t o_runs = carve(runs_entries * sizeof(Run));
+    b->arena_bytes = std::max<size_t>(off, 256);
+    if (hipMalloc(&b->arena, b->arena_bytes) != hipSuccess) { delete b; return PQD_ERR_DEVICE; }
+    uint8_t* a = static_cast<uint8_t*>(b->arena);
+    b->d_items = reinterpret_cast<DevPage*>(a + o_items);
+    b->d_results = reinterpret_cast<DevResult*>(a + o_results);
+    b->d_rle_tile_prefix = reinterpret_cast<uint64_t*>(a + o_rle_prefix);
+    Run* runs = reinterpret_cast<Run*>(a + o_runs);
+    for (DevPage& d : b->items) {
+        if (d.family == FAM_RLE) { d.runs = runs; runs += d.runs_cap; }
+    }
+
+    // ---- upload ----
+    bool ok = true;
+    if (n_items) ok = ok && hip_ok(hipMemcpy(b->d_items, b->items.data(), n_items * sizeof(DevPage), hipMemcpyHostToDevice));
+    ok = ok && hip_ok(hipMemset(b->d_results, 0, std::max<size_t>(1, n_items) * sizeof(DevResult)));
+    for (int f = 0; f < 16; f++) {
+        b->fam[f].dev = reinterpret_cast<uint32_t*>(a + o_fam[f]);
+        if (!b->fam[f].items.empty())
+            ok = ok && hip_ok(hipMemcpy(b->fam[f].dev, b->fam[f].items.data(), b->fam[f].items.size() * sizeof(uint32_t),
+                                        hipMemcpyHostToDevice));
+    }
+    ok = ok && hip_ok(hipMemcpy(b->d_rle_tile_prefix, rle_prefix.data(), rle_prefix.size() * sizeof(uint64_t),
+                                hipMemcpyHostToDevice));
+    if (!ok) { hipFree(b->arena); delete b; return PQD_ERR_DEVICE; }
+    b->h_results.resize(n_items);
+    *out = b;
+    return PQD_OK;
+}
+
+int pqd_batch_launch(pqd_batch* b, void* hip_stream) {
+    if (b == nullptr) return PQD_ERR_INVALID_ARGUMENT;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA32].dev, (uint32_t)b->fam[FAM_DELTA32].items.size(), false, s);
+    launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA64].dev, (uint32_t)b->fam[FAM_DELTA64].items.size(), true, s);
+    launch_rle_index(b->d_items, b->d_results, b->fam[FAM_RLE].dev, (uint32_t)b->fam[FAM_RLE].items.size(), s);
+    launch_rle_expand(b->d_items, b->d_results, b->fam[FAM_RLE].dev, (uint32_t)b->fam[FAM_RLE].items.size(),
+                      b->d_rle_tile_prefix, b->rle_tiles, s);
+    return hipGetLastError() == hipSuccess ? PQD_OK : PQD_ERR_DEVICE;
+}
+
+int pqd_batch_finish(pqd_batch* b, void* hip_stream, pqd_page* pages, uint64_t n_pages) {
+    if (b == nullptr || (pages == nullptr && n_pages > 0) || n_pages != b->n_pages) return PQD_ERR_INVALID_ARGUMENT;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    PQD_HIP(hipStreamSynchronize(s));
+    if (!b->items.empty())
+        PQD_HIP(hipMemcpy(b->h_results.data(), b->d_results, b->items.size() * sizeof(DevResult), hipMemcpyDeviceToHost));
+    for (uint64_t i = 0; i < n_pages; i++) {
+        const PageMap& m = b->map[i];
+        pqd_page& p = pages[i];
+        p.reserved = 0;
+        if (m.primary < 0) {
+            p.status = m.host_status;
+            p.status_arg = m.host_arg;
+            p.out_values = p.out_bytes = p.consumed = 0;
+            continue;
+        }
+        const DevResult& r = b->h_results[m.primary];
+        const DevPage& d = b->items[m.primary];
+        p.status = r.status;
+        p.status_arg = r.arg;
+        p.out_values = r.out_values;
+        p.out_bytes = r.out_bytes;
+        p.consumed = r.consumed;
+        if (d.family == FAM_RLE && d.fused && r.status == PQD_OK && r.aux != ~0ull) {
+            p.status = PQD_ERR_INDEX_OUT_OF_BOUNDS; // the reference panics here (errors.go:75-83)
+            p.status_arg = (int64_t)r.aux;
+        }
+    }
+    return PQD_OK;
+}
+
+void pqd_batch_destroy(pqd_batch* b) {
+    if (b == nullptr) return;
+    if (b->arena) (void)hipFree(b->arena);
+    delete b;
+}
+
+int pqd_decode_batch(pqd_ctx* ctx, pqd_page* pages, uint64_t n_pages, void* hip_stream) {
+    pqd_batch* b = nullptr;
+    int rc = pqd_batch_create(ctx, pages, n_pages, &b);
+    if (rc != PQD_OK) return rc;
+    rc = pqd_batch_launch(b, hip_stream);
+    if (rc == PQD_OK) rc = pqd_batch_finish(b, hip_stream, pages, n_pages);
+    pqd_batch_destroy(b);
+    return rc;
+}
+
+} // extern "C"

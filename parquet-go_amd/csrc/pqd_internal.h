@@ -1,0 +1,103 @@
+// pqd_internal.h -- device-side descriptors shared by the kernels and the host API.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pqd.h"
+
+// Opaque handles of the C ABI.
+struct pqd_ctx {
+    int device;
+};
+
+struct pqd_dict {
+    pqd_ctx* ctx;
+    void* values;   // device copy of the dictionary values
+    uint64_t n;
+    uint32_t width;
+};
+
+namespace pqd {
+
+// One entry of a run table built by the RLE index kernel.
+struct Run {
+    uint32_t out_start;  // first output value of the run
+    uint32_t in_off;     // byte offset in src of the packed data (bit-packed runs)
+    uint32_t value;      // repeated value (RLE runs)
+    uint32_t count_kind; // count << 1 | bitpacked
+};
+
+// Device copy of a work item plus the scratch the batch assigned to it.
+struct DevPage {
+    const uint8_t* src;
+    uint64_t src_len;
+    uint8_t* dst;
+    uint64_t dst_cap;
+    uint32_t* offsets;
+    uint64_t offsets_cap;
+    const uint8_t* dict;
+    uint64_t dict_len;
+    int64_t num_values;
+    int32_t encoding;
+    int32_t kind;
+    int32_t bit_width;
+    int32_t dst_stride;
+    // scratch
+    Run* runs;          // RLE run table
+    uint64_t runs_cap;
+    int32_t* lengths;   // DELTA length streams (prefix / lengths)
+    int32_t* lengths2;  // DELTA_BYTE_ARRAY suffix lengths
+    uint64_t lengths_cap; // entries each
+    uint64_t tile_base;   // first tile of this page in its family's tile grid
+    int32_t elem_width;   // output element width in bytes
+    int32_t family;       // kernel family
+    int32_t chain;        // index of the item whose `consumed` gives this item's src offset, or -1
+    int32_t fused;        // RLE family: indices go straight through the dictionary gather
+};
+
+struct DevResult {
+    int32_t status;
+    int32_t bw;        // RLE: effective bit width (first byte of a dictionary-index page)
+    int64_t arg;
+    uint64_t out_values;
+    uint64_t out_bytes;
+    uint64_t consumed;
+    uint64_t n_runs;   // RLE: runs in the table
+    uint64_t total;    // RLE: values the stream holds; DELTA: header total
+    uint64_t aux;      // family specific
+};
+
+enum Family : int32_t {
+    FAM_NONE = 0,
+    FAM_DELTA32 = 1,
+    FAM_DELTA64 = 2,
+    FAM_RLE = 3,        // levels, int32, fused dictionary
+    FAM_RLE_BOOL = 4,
+    FAM_BITPACKED = 5,
+    FAM_BSS = 6,
+    FAM_PLAIN_FIXED = 7,
+    FAM_PLAIN_BYTE_ARRAY = 8,
+    FAM_DLBA = 9,
+    FAM_DBA = 10,
+    FAM_ERROR = 11      // rejected on the host; status already set
+};
+
+// Failure bookkeeping: the first failing condition in stream order wins; a
+// kernel records one with this helper from a single thread.
+__device__ inline void set_status(DevResult* r, int32_t status, int64_t arg) {
+    r->status = status;
+    r->arg = arg;
+}
+
+// Kernel launchers (defined in the .hip files).
+void launch_delta(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, bool is64,
+                  hipStream_t stream);
+void launch_rle_index(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
+                      hipStream_t stream);
+void launch_rle_expand(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
+                       const uint64_t* tile_prefix, uint64_t n_tiles, hipStream_t stream);
+
+constexpr uint32_t RLE_TILE = 2048; // output values per expand workgroup
+
+} // namespace pqd

@@ -1,0 +1,449 @@
+// rle.hip -- RLE / bit-packed hybrid decode for gfx950, with the dictionary
+// gather fused in.
+//
+// Replaces rle.Encoding.DecodeLevels / DecodeBoolean / DecodeInt32,
+// rle.DictionaryEncoding.DecodeInt32 (reference: encoding/rle/rle.go:63-88,
+// 251-419,550-576; encoding/rle/dictionary.go:30-37; on amd64
+// decodeBytesBitpackBMI2, encoding/rle/rle_amd64.s:16-35, and bitpack.Unpack)
+// and, for dictionary pages, newIndexedPage + Dictionary.Lookup
+// (dictionary.go:136-162,230-243; dictionaryLookup32/64,
+// dictionary_amd64.s:578-711).
+//
+// Two kernels per batch:
+//   rle_index   one wavefront per page walks the run headers (each header's
+//               position depends on the ones before it) out of an LDS ring and
+//               writes a run table {out_start, in_off, value, count|kind}.
+//   rle_expand  a grid over OUTPUT tiles of 2048 values, so work is balanced
+//               by output size, not by run count.  A tile inside one bit-packed
+//               run stages its packed bytes through LDS with aligned 16-byte
+//               loads and every lane extracts its fields from two LDS dwords;
+//               mixed tiles look their runs up in an LDS copy of the table.
+//               With a dictionary the index goes straight to the gather and is
+//               never written to memory.
+#include "pqd_internal.h"
+
+namespace pqd {
+namespace {
+
+// ------------------------------------------------------------------ index --
+
+constexpr int IT = 64;                       // one wavefront
+constexpr uint32_t IRING_BYTES = 4096;
+constexpr uint32_t IRING_MASK = IRING_BYTES - 1;
+constexpr uint32_t ICHUNK = IT * 16;
+constexpr uint32_t ILOOK = 3 * ICHUNK;
+constexpr uint32_t MAX_TOTAL = 0x7fffffffu;  // values one page may decode to
+
+enum Mode : int32_t { MODE_LEVELS = 0, MODE_INT32 = 1, MODE_BOOL = 2 };
+
+struct ICtl {
+    uint64_t pos;
+    uint64_t n_runs;
+    uint64_t total;
+    int64_t arg;
+    int32_t status;
+    int32_t done;
+};
+
+__device__ inline int iring_uvarint(const uint8_t* ring8, uint64_t pos, uint64_t end, uint64_t* out) {
+    uint64_t x = 0;
+    unsigned s = 0;
+    for (int i = 0;; i++) {
+        if (pos + i >= end) { *out = 0; return 0; }
+        if (i == 10) return -(i + 1);
+        uint32_t b = ring8[(pos + i) & IRING_MASK];
+        if (b < 0x80) {
+            if (i == 9 && b > 1) return -(i + 1);
+            *out = x | ((uint64_t)b << s);
+            return i + 1;
+        }
+        x |= (uint64_t)(b & 0x7f) << s;
+        s += 7;
+    }
+}
+
+__global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                      const uint32_t* __restrict__ items) {
+    __shared__ uint32_t ring[IRING_BYTES / 4];
+    __shared__ ICtl ctl;
+    const uint32_t item = items[blockIdx.x];
+    const DevPage& pg = pages[item];
+    DevResult* res = &results[item];
+    const uint32_t tid = threadIdx.x;
+    const uint8_t* ring8 = reinterpret_cast<const uint8_t*>(ring);
+
+    const uint8_t* src = pg.src;
+    uint64_t src_len = pg.src_len;
+    int32_t mode = pg.kind == PQD_KIND_LEVELS ? MODE_LEVELS : (pg.kind == PQD_KIND_BOOLEAN ? MODE_BOOL : MODE_INT32);
+    const bool dict_framed = pg.encoding == PQD_ENC_RLE_DICTIONARY || pg.encoding == PQD_ENC_PLAIN_DICTIONARY;
+    uint32_t bw = (uint32_t)pg.bit_width;
+    uint64_t start = 0;
+    int32_t status0 = PQD_OK;
+    int64_t arg0 = 0;
+    if (dict_framed) {
+        // rle/dictionary.go:30-37: first byte is the bit width; empty input is an empty page
+        mode = MODE_INT32;
+        if (src_len == 0) { bw = 0; } else { bw = src[0]; start = 1; }
+    } else if (mode == MODE_BOOL) {
+        // rle.go:68-82: 4-byte little-endian length prefix
+        bw = 8;
+        if (src_len == 4) { src_len = 0; }
+        else if (src_len < 4) { status0 = PQD_ERR_UNEXPECTED_EOF; arg0 = PQD_EOF_LENGTH_PREFIX; src_len = 0; }
+        else {
+            uint64_t n = (uint64_t)src[0] | ((uint64_t)src[1] << 8) | ((uint64_t)src[2] << 16) | ((uint64_t)src[3] << 24);
+            if (n > src_len - 4) { status0 = PQD_ERR_UNEXPECTED_EOF; arg0 = PQD_EOF_LENGTH_PREFIX; src_len = 0; }
+            else { start = 4; src_len = 4 + n; }
+        }
+    }
+    if (status0 == PQD_OK) {
+        if (mode == MODE_LEVELS && bw > 8) { status0 = PQD_ERR_INVALID_BIT_WIDTH; arg0 = bw; }
+        if (mode == MODE_INT32 && bw > 32) { status0 = PQD_ERR_INVALID_BIT_WIDTH; arg0 = bw; }
+    }
+    if (status0 != PQD_OK) src_len = 0;
+
+    const uint64_t mis = reinterpret_cast<uintptr_t>(src) & 15;
+    const uint8_t* base = src - mis;
+    const uint64_t end = mis + src_len;
+    if (tid == 0) {
+        ctl.pos = mis + start;
+        ctl.n_runs = 0;
+        ctl.total = 0;
+        ctl.status = status0;
+        ctl.arg = arg0;
+        ctl.done = (mis + start >= end) ? 1 : 0;
+    }
+    __syncthreads();
+
+    uint64_t c_next = 0;
+    Run* runs = pg.runs;
+    while (!ctl.done) {
+        // fill the ring so that [pos, pos + ILOOK) is resident
+        const uint64_t pos0 = ctl.pos;
+        uint64_t c_lo = pos0 / ICHUNK;
+        if (c_next < c_lo) c_next = c_lo;
+        while (c_next <= c_lo + ILOOK / ICHUNK) {
+            uint64_t v = c_next * ICHUNK + tid * 16u;
+            uint4 w = make_uint4(0, 0, 0, 0);
+            if (v < end) w = *reinterpret_cast<const uint4*>(base + v); // bytes past `end` are never parsed
+            *reinterpret_cast<uint4*>(&ring[(v & IRING_MASK) >> 2]) = w;
+            c_next++;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            uint64_t pos = pos0;
+            const uint64_t covered = (c_lo + ILOOK / ICHUNK + 1) * ICHUNK;
+            uint64_t n_runs = ctl.n_runs, total = ctl.total;
+            int32_t status = PQD_OK;
+            int64_t arg = 0;
+            while (pos < end) {
+                if (pos + 16 > covered && covered < end) break; // header might straddle the resident window
+                uint64_t u;
+                int k = iring_uvarint(ring8, pos, end, &u);
+                if (k == 0) { status = PQD_ERR_UNEXPECTED_EOF; arg = PQD_EOF_RUN_HEADER; break; }
+                if (k < 0) { status = PQD_ERR_VARINT_OVERFLOW; arg = (int64_t)(pos - mis - start); break; }
+                pos += k;
+                uint64_t count = u >> 1;
+                const bool bitpacked = (u & 1) != 0;
+                if (count == 0) continue; // empty runs carry no value byte (rle.go:311-313)
+                if (count > 0x7fffffffull) { status = PQD_ERR_RUN_TOO_LARGE; arg = (int64_t)count; break; }
+                Run r;
+                r.out_start = (uint32_t)total;
+                r.in_off = 0;
+                r.value = 0;
+                uint64_t nvals;
+                if (bitpacked) {
+                    uint64_t nbytes;
+                    if (mode == MODE_BOOL) { nbytes = count; nvals = count; }      // header counts bytes
+                    else { nbytes = count * bw; nvals = count * 8; }
+                    if (nbytes > end - pos) { status = PQD_ERR_UNEXPECTED_EOF; arg = PQD_EOF_BITPACKED_RUN; break; }
+                    r.in_off = (uint32_t)(pos - mis);
+                    pos += nbytes;
+                } else if (mode == MODE_BOOL) {
+                    uint32_t word = 0;
+                    if (pos < end) word = ring8[pos++ & IRING_MASK];
+                    r.value = word;
+                    nvals = (count + 7) / 8; // bytes of output
+                } else {
+                    uint32_t vb = mode == MODE_LEVELS ? (bw != 0 ? 1u : 0u) : (bw + 7) / 8;
+                    if (vb > end - pos) { status = PQD_ERR_UNEXPECTED_EOF; arg = PQD_EOF_RLE_VALUE; break; }
+                    uint32_t value = 0;
+                    for (uint32_t b = 0; b < vb; b++) value |= (uint32_t)ring8[(pos + b) & IRING_MASK] << (8 * b);
+                    pos += vb;
+                    r.value = value;
+                    nvals = count;
+                }
+                if (total + nvals > MAX_TOTAL) { status = PQD_ERR_RUN_TOO_LARGE; arg = (int64_t)(total + nvals); break; }
+                r.count_kind = ((uint32_t)nvals << 1) | (bitpacked ? 1u : 0u);
+                runs[n_runs++] = r;
+                total += nvals;
+            }
+            ctl.pos = pos;
+            ctl.n_runs = n_runs;
+            ctl.total = total;
+            if (status != PQD_OK) { ctl.status = status; ctl.arg = arg; ctl.done = 1; }
+            else if (pos >= end) ctl.done = 1;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        res->status = ctl.status;
+        res->bw = (int32_t)bw;
+        res->arg = ctl.arg;
+        res->n_runs = ctl.n_runs;
+        res->total = ctl.total;
+        res->consumed = ctl.pos >= mis ? ctl.pos - mis : 0;
+        res->out_values = 0;
+        res->out_bytes = 0;
+        res->aux = ~0ull; // position of the first out-of-range dictionary index
+    }
+}
+
+// ----------------------------------------------------------------- expand --
+
+constexpr int ET = 256;
+constexpr uint32_t STAGE_BYTES = RLE_TILE * 4 + 64; // packed bytes of one tile at 32 bits per value, plus slack
+constexpr uint32_t MAX_TILE_RUNS = RLE_TILE + 2;
+
+struct EShared {
+    uint32_t stage[STAGE_BYTES / 4];
+    uint32_t run_start[MAX_TILE_RUNS];
+};
+
+// Number of values the item writes, after the caller's length fix-up
+// (dictionary.go:136-162; column.go:940-945).
+__device__ inline uint64_t output_count(const DevPage& pg, uint64_t total, bool fused) {
+    if (pg.num_values < 0) return total;
+    uint64_t nv = (uint64_t)pg.num_values;
+    if (fused) return nv;            // short streams are zero-extended
+    return total < nv ? total : nv;  // longer streams are cut
+}
+
+template <int ELEM, bool FUSED>
+__device__ inline void store_value(const DevPage& pg, DevResult* res, uint64_t pos, uint32_t v, uint32_t stride) {
+    uint8_t* p = pg.dst + pos * stride;
+    if (!FUSED) {
+        if (ELEM == 1) *p = (uint8_t)v;
+        else *reinterpret_cast<uint32_t*>(p) = v;
+        return;
+    }
+    // Dictionary.Lookup: unsigned bounds check, then gather (dictionary_amd64.s:578-711)
+    const bool ok = (uint64_t)v < pg.dict_len;
+    if (!ok) atomicMin(reinterpret_cast<unsigned long long*>(&res->aux), (unsigned long long)pos);
+    const uint8_t* d = pg.dict + (uint64_t)(ok ? v : 0) * ELEM;
+    if (ELEM == 4) {
+        uint32_t x = ok ? *reinterpret_cast<const uint32_t*>(d) : 0u;
+        *reinterpret_cast<uint32_t*>(p) = x;
+    } else if (ELEM == 8) {
+        uint64_t x = ok ? *reinterpret_cast<const uint64_t*>(d) : 0ull;
+        __builtin_memcpy(p, &x, 8);
+    } else {
+        const uint32_t* d32 = reinterpret_cast<const uint32_t*>(d);
+        uint32_t* p32 = reinterpret_cast<uint32_t*>(p);
+        for (int k = 0; k < ELEM / 4; k++) p32[k] = ok ? d32[k] : 0u;
+    }
+}
+
+// Decodes the tile [t0, t0 + n) of one item.
+template <int ELEM, bool FUSED>
+__device__ inline void expand_tile(EShared& sh, const DevPage& pg, DevResult* res, uint64_t t0, uint32_t n,
+                                   uint64_t total, uint64_t n_runs, uint32_t bw) {
+    const uint32_t tid = threadIdx.x;
+    const Run* __restrict__ runs = pg.runs;
+    const uint32_t stride = pg.dst_stride > 0 ? (uint32_t)pg.dst_stride : (uint32_t)ELEM;
+    const bool dense = stride == (uint32_t)ELEM;
+    const uint64_t src_skip = 0;
+    const uint8_t* src = pg.src + src_skip;
+
+    // values past the end of the stream: zero-extended indices (FUSED only)
+    uint32_t n_stream = n;
+    if (t0 >= total) n_stream = 0;
+    else if (t0 + n > total) n_stream = (uint32_t)(total - t0);
+
+    // ---- locate the run holding t0 (uniform binary search) ----
+    uint64_t r0 = 0;
+    if (n_stream > 0) {
+        uint64_t lo = 0, hi = n_runs; // last run with out_start <= t0
+        while (hi - lo > 1) {
+            uint64_t mid = (lo + hi) >> 1;
+            if ((uint64_t)runs[mid].out_start <= t0) lo = mid; else hi = mid;
+        }
+        r0 = lo;
+    }
+    Run first = {0, 0, 0, 0};
+    if (n_stream > 0) first = runs[r0];
+    const uint64_t first_end = (uint64_t)first.out_start + (first.count_kind >> 1);
+    const bool single = n_stream > 0 && first_end >= t0 + n_stream;
+
+    // thread -> value mapping: G consecutive values per thread and repetition,
+    // chosen so one store instruction of a wave covers contiguous memory
+    constexpr int G = ELEM == 1 ? 8 : (ELEM == 8 ? 2 : 4);
+    constexpr int R = 8 / G;
+
+    if (single && (first.count_kind & 1)) {
+        // ---- fast path: the whole tile lies inside one bit-packed run ----
+        const uint64_t k0 = t0 - first.out_start;            // first field of the tile within the run
+        const uint64_t bit0 = k0 * bw;
+        const uint64_t byte0 = (uint64_t)first.in_off + (bit0 >> 3);
+        const uint64_t byte1 = (uint64_t)first.in_off + ((bit0 + (uint64_t)n_stream * bw + 7) >> 3);
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(src + byte0);
+        const uint64_t mis = a0 & 15;
+        const uint8_t* abase = reinterpret_cast<const uint8_t*>(a0 - mis);
+        const uint64_t span = mis + (byte1 - byte0);        // bytes to stage, from the aligned base
+        for (uint32_t c = tid * 16; c < span; c += ET * 16) {
+            uint4 w = *reinterpret_cast<const uint4*>(abase + c);
+            *reinterpret_cast<uint4*>(&sh.stage[c >> 2]) = w;
+        }
+        __syncthreads();
+        const uint32_t bitbase = (uint32_t)(mis * 8 + (bit0 & 7));
+        const uint32_t mask = bw >= 32 ? 0xffffffffu : ((1u << bw) - 1);
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const uint32_t j = r * (ET * G) + tid * G;
+            uint32_t v[G];
+#pragma unroll
+            for (int g = 0; g < G; g++) {
+                uint32_t b = bitbase + (j + g) * bw;
+                uint32_t k = b >> 5, s = b & 31;
+                uint64_t w01 = (uint64_t)sh.stage[k] | ((uint64_t)sh.stage[k + 1] << 32);
+                v[g] = (uint32_t)(w01 >> s) & mask;
+            }
+            if (!FUSED && dense && j + G <= n_stream) {
+                uint8_t* p = pg.dst + (t0 + j) * ELEM;
+                if (ELEM == 1) {
+                    uint32_t lo = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+                    uint32_t hi = v[4 % G] | (v[5 % G] << 8) | (v[6 % G] << 16) | (v[7 % G] << 24);
+                    uint2 w = make_uint2(lo, hi);
+                    __builtin_memcpy(p, &w, 8);
+                } else {
+                    uint4 w = make_uint4(v[0], v[1 % G], v[2 % G], v[3 % G]);
+                    __builtin_memcpy(p, &w, 16);
+                }
+            } else if (FUSED && dense && ELEM == 8 && j + G <= n_stream) {
+                // gather two 8-byte values, store 16 contiguous bytes
+                uint64_t x[2];
+#pragma unroll
+                for (int g = 0; g < 2; g++) {
+                    const uint32_t idx = v[g % G];
+                    const bool ok = (uint64_t)idx < pg.dict_len;
+                    if (!ok) atomicMin(reinterpret_cast<unsigned long long*>(&res->aux), (unsigned long long)(t0 + j + g));
+                    x[g] = ok ? reinterpret_cast<const uint64_t*>(pg.dict)[idx] : 0ull;
+                }
+                __builtin_memcpy(pg.dst + (t0 + j) * 8, x, 16);
+            } else if (FUSED && dense && ELEM == 4 && j + G <= n_stream) {
+                uint32_t x[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const uint32_t idx = v[g % G];
+                    const bool ok = (uint64_t)idx < pg.dict_len;
+                    if (!ok) atomicMin(reinterpret_cast<unsigned long long*>(&res->aux), (unsigned long long)(t0 + j + g));
+                    x[g] = ok ? reinterpret_cast<const uint32_t*>(pg.dict)[idx] : 0u;
+                }
+                __builtin_memcpy(pg.dst + (t0 + j) * 4, x, 16);
+            } else {
+#pragma unroll
+                for (int g = 0; g < G; g++)
+                    if (j + g < n_stream) store_value<ELEM, FUSED>(pg, res, t0 + j + g, v[g], stride);
+            }
+        }
+    } else if (single) {
+        // ---- the whole tile lies inside one repeated run ----
+        for (uint32_t j = tid; j < n_stream; j += ET) store_value<ELEM, FUSED>(pg, res, t0 + j, first.value, stride);
+    } else if (n_stream > 0) {
+        // ---- mixed tile: stage the out_start of every run that intersects it ----
+        uint64_t avail = n_runs - r0;
+        uint32_t nr = avail < MAX_TILE_RUNS ? (uint32_t)avail : MAX_TILE_RUNS;
+        for (uint32_t k = tid; k < nr; k += ET) sh.run_start[k] = runs[r0 + k].out_start;
+        __syncthreads();
+        for (uint32_t j = tid; j < n_stream; j += ET) {
+            const uint64_t pos = t0 + j;
+            uint32_t lo = 0, hi = nr; // last staged run with out_start <= pos
+            while (hi - lo > 1) {
+                uint32_t mid = (lo + hi) >> 1;
+                if ((uint64_t)sh.run_start[mid] <= pos) lo = mid; else hi = mid;
+            }
+            const Run rr = runs[r0 + lo];
+            uint32_t v;
+            if (rr.count_kind & 1) {
+                // bytes touched all belong to this run, which the index kernel bounds-checked
+                uint64_t bit = (pos - rr.out_start) * bw;
+                const uint8_t* q = src + rr.in_off + (bit >> 3);
+                uint32_t s = (uint32_t)(bit & 7);
+                uint32_t nb = (s + bw + 7) >> 3;
+                uint64_t acc = 0;
+                for (uint32_t b = 0; b < nb; b++) acc |= (uint64_t)q[b] << (8 * b);
+                v = (uint32_t)(acc >> s) & (bw >= 32 ? 0xffffffffu : ((1u << bw) - 1));
+            } else {
+                v = rr.value;
+            }
+            store_value<ELEM, FUSED>(pg, res, pos, v, stride);
+        }
+    }
+    // zero-extended tail of a dictionary page
+    if (FUSED) {
+        for (uint32_t j = n_stream + tid; j < n; j += ET) store_value<ELEM, FUSED>(pg, res, t0 + j, 0u, stride);
+    }
+}
+
+__global__ __launch_bounds__(ET) void rle_expand_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                       const uint32_t* __restrict__ items, uint32_t n_items,
+                                                       const uint64_t* __restrict__ tile_prefix) {
+    __shared__ EShared sh;
+    // which item does this tile belong to: last i with tile_prefix[i] <= blockIdx.x
+    uint32_t lo = 0, hi = n_items;
+    const uint64_t b = blockIdx.x;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (tile_prefix[mid] <= b) lo = mid; else hi = mid;
+    }
+    const uint32_t item = items[lo];
+    const uint64_t tile = b - tile_prefix[lo];
+    const DevPage& pg = pages[item];
+    DevResult* res = &results[item];
+    const uint64_t total = res->total;
+    const uint64_t n_runs = res->n_runs;
+    const uint32_t bw = (uint32_t)res->bw;
+    const bool fused = pg.fused != 0;
+    const uint32_t elem = (uint32_t)pg.elem_width;
+    const uint32_t stride = pg.dst_stride > 0 ? (uint32_t)pg.dst_stride : elem;
+    uint64_t n_out = output_count(pg, total, fused);
+    const uint64_t fit = pg.dst_cap / stride + ((pg.dst_cap % stride) >= elem ? 1 : 0);
+    const uint64_t need_bytes = n_out == 0 ? 0 : (n_out - 1) * stride + elem;
+    bool too_small = false;
+    if (n_out > fit) { too_small = true; n_out = fit; }
+    if (tile == 0 && threadIdx.x == 0) {
+        res->out_values = n_out;
+        res->out_bytes = n_out == 0 ? 0 : (n_out - 1) * (uint64_t)stride + elem;
+        if (too_small && res->status == PQD_OK) { res->status = PQD_ERR_DST_TOO_SMALL; res->arg = (int64_t)need_bytes; }
+    }
+    const uint64_t t0 = tile * RLE_TILE;
+    if (t0 >= n_out) return;
+    const uint32_t n = n_out - t0 < RLE_TILE ? (uint32_t)(n_out - t0) : RLE_TILE;
+    if (fused) {
+        switch (elem) {
+            case 4: expand_tile<4, true>(sh, pg, res, t0, n, total, n_runs, bw); break;
+            case 8: expand_tile<8, true>(sh, pg, res, t0, n, total, n_runs, bw); break;
+            default: expand_tile<12, true>(sh, pg, res, t0, n, total, n_runs, bw); break;
+        }
+    } else if (elem == 1) {
+        expand_tile<1, false>(sh, pg, res, t0, n, total, n_runs, bw);
+    } else {
+        expand_tile<4, false>(sh, pg, res, t0, n, total, n_runs, bw);
+    }
+}
+
+} // namespace
+
+void launch_rle_index(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
+                      hipStream_t stream) {
+    if (n_items == 0) return;
+    hipLaunchKernelGGL(rle_index_kernel, dim3(n_items), dim3(IT), 0, stream, pages, results, items);
+}
+
+void launch_rle_expand(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
+                       const uint64_t* tile_prefix, uint64_t n_tiles, hipStream_t stream) {
+    if (n_items == 0 || n_tiles == 0) return;
+    hipLaunchKernelGGL(rle_expand_kernel, dim3((uint32_t)n_tiles), dim3(ET), 0, stream, pages, results, items, n_items,
+                       tile_prefix);
+}
+
+} // namespace pqd

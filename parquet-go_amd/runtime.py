@@ -1,0 +1,173 @@
+"""Device plumbing: torch owns HBM buffers and streams, libpqd does the work.
+
+`Batch` is a thin wrapper over pqd_batch_{create,launch,finish}: pages already
+in HBM go in, decoded values stay in HBM.  `decode_pages` is the convenience
+used by tests: host bytes in, numpy out, through the same batched entry points.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from ._lib import ENC, KIND, STATUS, Context, Page, PqdError, lib
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("no GPU visible: the decode path has no CPU fallback")
+    return torch
+
+
+class DeviceBuffer:
+    """A byte buffer in HBM (a torch uint8 tensor) with a few bytes of slack in front
+    so tests can place a page at any alignment."""
+
+    def __init__(self, nbytes: int, device: int = 0, misalign: int = 0, fill: Optional[int] = None):
+        torch = _torch()
+        self.nbytes = int(nbytes)
+        self.misalign = int(misalign)
+        n = self.nbytes + self.misalign + 64
+        self.t = torch.empty(n, dtype=torch.uint8, device=f"cuda:{device}")
+        if fill is not None:
+            self.t.fill_(fill)
+
+    @property
+    def ptr(self) -> int:
+        return self.t.data_ptr() + self.misalign
+
+    def view(self):
+        return self.t[self.misalign: self.misalign + self.nbytes]
+
+    def numpy(self) -> np.ndarray:
+        return self.view().cpu().numpy()
+
+
+def to_device(data, device: int = 0, misalign: int = 0) -> DeviceBuffer:
+    torch = _torch()
+    a = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+    buf = DeviceBuffer(a.size, device, misalign)
+    if a.size:
+        buf.view().copy_(torch.from_numpy(a.copy()))
+    return buf
+
+
+class Batch:
+    """pqd_batch over an array of `Page` descriptors holding device pointers."""
+
+    def __init__(self, ctx: Context, pages: Sequence[Page]):
+        self.ctx = ctx
+        self.n = len(pages)
+        self.pages = (Page * max(self.n, 1))(*pages)
+        h = C.c_void_p()
+        rc = lib().pqd_batch_create(ctx.handle, self.pages, self.n, C.byref(h))
+        if rc != STATUS.OK:
+            raise PqdError(rc, 0, "pqd_batch_create")
+        self.handle = h
+
+    def launch(self, stream: int = 0):
+        rc = lib().pqd_batch_launch(self.handle, C.c_void_p(stream))
+        if rc != STATUS.OK:
+            raise PqdError(rc, 0, "pqd_batch_launch")
+
+    def finish(self, stream: int = 0):
+        rc = lib().pqd_batch_finish(self.handle, C.c_void_p(stream), self.pages, self.n)
+        if rc != STATUS.OK:
+            raise PqdError(rc, 0, "pqd_batch_finish")
+        return self.pages
+
+    def close(self):
+        if self.handle:
+            lib().pqd_batch_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class PageSpec:
+    """A page to decode, host side: what a test hands to `decode_pages`."""
+    encoding: int
+    kind: int
+    src: bytes
+    bit_width: int = 0
+    num_values: int = -1
+    dst_cap: int = 0              # bytes; 0 = let decode_pages pick a generous bound
+    offsets_cap: int = 0          # entries
+    dictionary: Optional[np.ndarray] = None  # fixed-width dictionary values
+    dst_stride: int = 0
+    misalign: int = 0             # byte misalignment of src in device memory
+
+
+@dataclass
+class PageOut:
+    status: int
+    arg: int
+    out_values: int
+    out_bytes: int
+    consumed: int
+    data: np.ndarray              # dst bytes [0, out_bytes)
+    offsets: Optional[np.ndarray]
+    raw: Optional[np.ndarray] = None  # whole dst buffer (with canaries)
+
+
+_CANARY = 0xA5
+
+
+def decode_pages(ctx: Context, specs: List[PageSpec], device: int = 0, grow: bool = True) -> List[PageOut]:
+    """Uploads the pages, runs ONE batch, downloads results.  DST_TOO_SMALL items
+    are retried once with the size the library asked for, the way a Go caller
+    grows its slice."""
+    torch = _torch()
+    stream = torch.cuda.current_stream(device).cuda_stream
+    srcs, dsts, offs, dicts, pages = [], [], [], [], []
+    for s in specs:
+        src = to_device(s.src, device, s.misalign)
+        cap = s.dst_cap or max(4096, 80 * len(s.src) + 4096)
+        dst = DeviceBuffer(cap + 64, device, fill=_CANARY)
+        ocap = s.offsets_cap or (len(s.src) + 8 if s.kind == KIND.BYTE_ARRAY else 0)
+        off = DeviceBuffer(ocap * 4 + 64, device, fill=_CANARY) if ocap else None
+        d = to_device(s.dictionary, device) if s.dictionary is not None else None
+        p = Page()
+        p.src, p.src_len = src.ptr, len(s.src)
+        p.dst, p.dst_cap = dst.ptr, cap
+        p.offsets, p.offsets_cap = (off.ptr if off else None), ocap
+        p.dict, p.dict_len = (d.ptr if d is not None else None), (len(s.dictionary) if s.dictionary is not None else 0)
+        if d is not None and p.dict_len == 0:
+            p.dict = d.ptr
+        p.num_values = s.num_values
+        p.encoding, p.kind, p.bit_width, p.dst_stride = s.encoding, s.kind, s.bit_width, s.dst_stride
+        srcs.append(src); dsts.append(dst); offs.append(off); dicts.append(d); pages.append(p)
+    b = Batch(ctx, pages)
+    b.launch(stream)
+    res = b.finish(stream)
+    outs = []
+    for i, s in enumerate(specs):
+        r = res[i]
+        raw = dsts[i].numpy()
+        cap = pages[i].dst_cap
+        # nothing may be written past the capacity handed in
+        assert (raw[cap:] == _CANARY).all(), f"page {i}: write past dst_cap"
+        o = offs[i].numpy().view(np.uint32) if offs[i] is not None else None
+        if o is not None:
+            ocap = pages[i].offsets_cap
+            assert (o[ocap:] == 0xA5A5A5A5).all(), f"page {i}: write past offsets_cap"
+        outs.append(PageOut(r.status, r.status_arg, r.out_values, r.out_bytes, r.consumed,
+                            raw[: min(r.out_bytes, cap)].copy(), None if o is None else o.copy(), raw))
+    b.close()
+    if grow:
+        for i, s in enumerate(specs):
+            if outs[i].status == STATUS.DST_TOO_SMALL and outs[i].arg > (s.dst_cap or 0):
+                s2 = PageSpec(**{**s.__dict__, "dst_cap": int(outs[i].arg)})
+                outs[i] = decode_pages(ctx, [s2], device, grow=False)[0]
+            elif outs[i].status == STATUS.OFFSETS_TOO_SMALL:
+                s2 = PageSpec(**{**s.__dict__, "offsets_cap": int(outs[i].arg)})
+                outs[i] = decode_pages(ctx, [s2], device, grow=True)[0]
+    return outs

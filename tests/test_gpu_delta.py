@@ -1,0 +1,165 @@
+"""GPU parity: DELTA_BINARY_PACKED through the C ABI against the CPU checker.
+
+Mirrors the reference's delta tests (encoding/encoding_test.go tables,
+encoding/delta/delta_test.go width x N sweep, the parquet test files) with the
+GPU kernel in the place of the Go decoder.  Bit exact.
+"""
+import numpy as np
+import pytest
+
+from oracle import pqoracle as O
+from tests import fixtures as F
+from tests import refdata as R
+from tests.gpu_util import assert_same, decode, pkg, spec
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(cases, kind, dtype, oracle_fn, values=True):
+    """cases: list of (label, encoded bytes, misalign)."""
+    P = pkg()
+    specs = [spec(P.ENC.DELTA_BINARY_PACKED, kind, enc, misalign=mis) for _, enc, mis in cases]
+    outs = decode(specs)
+    for (label, enc, _), out in zip(cases, outs):
+        want = oracle_fn(enc)
+        assert_same(out, want, dtype, label, values=values)
+        if want.status in (0, 9):  # the remainder is only meaningful when the stream parsed
+            assert out.consumed == want.consumed, f"{label}: consumed {out.consumed} != {want.consumed}"
+
+
+def _pm(i, bw):
+    v = -i if i % 2 else i
+    return v & ((1 << bw) - 1)
+
+
+def test_int64_reference_tables():
+    P = pkg()
+    cases = [(f"table{k}", O.delta_encode_int64(np.array(v, np.int64)), k % 16) for k, v in enumerate(R.INT64_TESTS)]
+    _run(cases, P.KIND.INT64, np.int64, O.delta_decode_int64)
+
+
+def test_int32_reference_tables():
+    P = pkg()
+    cases = [(f"table{k}", O.delta_encode_int32(np.array(v, np.int32)), k % 16) for k, v in enumerate(R.INT32_TESTS)]
+    _run(cases, P.KIND.INT32, np.int32, O.delta_decode_int32)
+
+
+def test_int64_width_sweep():
+    # delta_test.go:46-57: every bit width 0..64, N over 0..200
+    P = pkg()
+    cases = []
+    for bw in range(0, 65):
+        for n in (0, 1, 2, 3, 31, 32, 33, 34, 127, 128, 129, 130, 161, 200):
+            v = np.array([_pm(i, bw) for i in range(n)], np.uint64).view(np.int64)
+            cases.append((f"bw{bw}-n{n}", O.delta_encode_int64(v), (bw + n) % 16))
+    _run(cases, P.KIND.INT64, np.int64, O.delta_decode_int64)
+
+
+def test_int32_width_sweep():
+    P = pkg()
+    cases = []
+    for bw in range(0, 33):
+        for n in (0, 1, 2, 3, 31, 32, 33, 34, 127, 128, 129, 130, 161, 200):
+            v = np.array([_pm(i, bw) for i in range(n)], np.uint64).astype(np.uint32).view(np.int32)
+            cases.append((f"bw{bw}-n{n}", O.delta_encode_int32(v), (bw * 3 + n) % 16))
+    _run(cases, P.KIND.INT32, np.int32, O.delta_decode_int32)
+
+
+def test_quick_sizes_random():
+    # internal/quick sizes, random full-range values (wrapping arithmetic)
+    P = pkg()
+    rng = np.random.default_rng(0)
+    cases = []
+    for n in R.QUICK_SIZES:
+        v = rng.integers(-2**63, 2**63 - 1, size=n, dtype=np.int64)
+        cases.append((f"n{n}", O.delta_encode_int64(v), n % 16))
+    _run(cases, P.KIND.INT64, np.int64, O.delta_decode_int64)
+    cases = []
+    for n in R.QUICK_SIZES:
+        v = rng.integers(-2**31, 2**31 - 1, size=n, dtype=np.int32)
+        cases.append((f"n{n}", O.delta_encode_int32(v), n % 16))
+    _run(cases, P.KIND.INT32, np.int32, O.delta_decode_int32)
+
+
+def test_parquet_file_pages():
+    # pages cut from testdata/delta_binary_packed.parquet & co, expected values from pyarrow
+    P = pkg()
+    items = list(F.pages(kind=("v1", "v2"), encoding=(5,)))
+    assert len(items) > 70
+    specs = []
+    for k, (rec, a) in enumerate(items):
+        kind = P.KIND.INT64 if rec["physical_type"] == "INT64" else P.KIND.INT32
+        specs.append(spec(P.ENC.DELTA_BINARY_PACKED, kind, a["values"].tobytes(), misalign=k % 16))
+    outs = decode(specs)
+    for (rec, a), out in zip(items, outs):
+        dt = np.int64 if rec["physical_type"] == "INT64" else np.int32
+        assert out.status == 0, F.page_id(rec)
+        assert np.array_equal(out.data.view(dt), a["expected_values"]), F.page_id(rec)
+
+
+def test_large_pages_and_shapes():
+    P = pkg()
+    rng = np.random.default_rng(1)
+    cases = []
+    # timestamps like the benchmark column, one full-size page
+    ts = np.cumsum(rng.integers(1_000_000, 1_004_096, size=131072, dtype=np.int64)) + 1_600_000_000_000_000_000
+    cases.append(("timestamps", O.delta_encode_int64(ts), 3))
+    # widths changing from block to block
+    parts = [rng.integers(0, 1 << int(b), size=300, dtype=np.int64) for b in rng.integers(1, 62, size=40)]
+    cases.append(("mixed-widths", O.delta_encode_int64(np.cumsum(np.concatenate(parts))), 9))
+    cases.append(("constant", O.delta_encode_int64(np.full(5000, 7, np.int64)), 0))
+    cases.append(("minmax", O.delta_encode_int64(np.array(([-2**63, 2**63 - 1] * 700), np.int64)), 5))
+    for block, mbs in [(128, 1), (128, 2), (256, 8), (256, 2), (384, 4), (1024, 4), (2048, 64), (4096, 128), (65536, 1), (65536, 4)]:
+        v = rng.integers(-2**40, 2**40, size=3 * block + 17 if block < 65536 else 70000, dtype=np.int64)
+        cases.append((f"block{block}-mb{mbs}", O.delta_encode_int64(v, block, mbs), (block + mbs) % 16))
+    _run(cases, P.KIND.INT64, np.int64, O.delta_decode_int64)
+    cases = []
+    for block, mbs in [(128, 4), (256, 8), (384, 4), (1024, 2), (65536, 2)]:
+        v = rng.integers(-2**31, 2**31 - 1, size=2 * block + 5 if block < 65536 else 66000, dtype=np.int32)
+        cases.append((f"i32-block{block}-mb{mbs}", O.delta_encode_int32(v, block, mbs), mbs))
+    _run(cases, P.KIND.INT32, np.int32, O.delta_decode_int32)
+
+
+def test_errors_and_truncation():
+    P = pkg()
+    v = np.cumsum(np.arange(1000, dtype=np.int64) ** 2)
+    full = O.delta_encode_int64(v)
+    cases = [("empty", b"", 0)]
+    for cut in (1, 2, 3, 4, 5, 6, 7, 20, 100, len(full) // 2, len(full) - 200, len(full) - 3, len(full) - 1):
+        cases.append((f"cut{cut}", full[:cut], cut % 16))
+    cases += [
+        ("zero-miniblocks", bytes([0x80, 0x01, 0x00, 0x01, 0x00]), 0),
+        ("block-127", bytes([0x7f, 0x04, 0x01, 0x00]), 1),
+        ("block-too-large", bytes([0x80, 0x81, 0x04, 0x04, 0x01, 0x00]), 2),
+        ("miniblock-not-32", bytes([0x80, 0x01, 0x03, 0x01, 0x00]), 3),
+        ("too-many-values", bytes([0x80, 0x01, 0x04, 0x80, 0x80, 0x80, 0x80, 0x08, 0x00]), 4),
+        ("negative-total", bytes([0x80, 0x01, 0x04]) + b"\xff" * 9 + b"\x01\x00", 5),
+        ("header-overflow", b"\x80" * 11, 6),
+        ("zero-values", bytes([0x80, 0x01, 0x04, 0x00, 0x00]), 7),
+        ("one-value", bytes([0x80, 0x01, 0x04, 0x01, 0x05]), 8),
+        ("missing", bytes([0x80, 0x01, 0x04, 0x05, 0x02]), 9),
+        ("min-delta-overflow", bytes([0x80, 0x01, 0x04, 0x05, 0x02]) + b"\x80" * 11, 10),
+        ("short-widths", bytes([0x80, 0x01, 0x04, 0x40, 0x02, 0x02, 0x03]), 11),
+        ("more-miniblocks-than-values", bytes([0x80, 0x01, 0x80, 0x02, 0x05, 0x00]) + b"\x00" * 700, 12),
+    ]
+    _run(cases, P.KIND.INT64, np.int64, O.delta_decode_int64)
+    # a width above the value width: status only (the reference hands it to bitpack.Unpack)
+    bad = bytearray(O.delta_encode_int64(np.arange(300, dtype=np.int64)))
+    hdr = 5 if bad[3] < 0x80 else 6
+    bad[hdr + 1] = 65
+    _run([("width65", bytes(bad), 0)], P.KIND.INT64, np.int64, O.delta_decode_int64, values=False)
+    cases = [("i32-first-range", bytes([0x80, 0x01, 0x04, 0x01]) + b"\x80\x80\x80\x80\x20", 0)]
+    v32 = np.cumsum(np.arange(500, dtype=np.int32))
+    f32 = O.delta_encode_int32(v32)
+    for cut in (3, 9, len(f32) // 2, len(f32) - 1):
+        cases.append((f"i32-cut{cut}", f32[:cut], cut % 16))
+    _run(cases, P.KIND.INT32, np.int32, O.delta_decode_int32)
+
+
+def test_dst_too_small_reports_needed_size():
+    P = pkg()
+    v = np.arange(1000, dtype=np.int64)
+    out = decode([spec(P.ENC.DELTA_BINARY_PACKED, P.KIND.INT64, O.delta_encode_int64(v), dst_cap=4000)], grow=False)[0]
+    assert out.status == P.STATUS.DST_TOO_SMALL and out.arg == 8000
+    out = decode([spec(P.ENC.DELTA_BINARY_PACKED, P.KIND.INT64, O.delta_encode_int64(v), dst_cap=8000)], grow=False)[0]
+    assert out.status == 0 and np.array_equal(out.data.view(np.int64), v)
