@@ -1,0 +1,375 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X page-value decode path.
+
+Metric (BASELINE.json): device-resident decoded GB/s per GPU & node, RLE-dict + DELTA int64 pages.
+Headline workload at N=1 (BASELINE.json configs[1]): DELTA_BINARY_PACKED int64 timestamps,
+256 Mi values in 2048 pages of 131072, blocks of 128 / 4 miniblocks, deltas 1e6 + U[0,4096) ns.
+A step is one pass of the decode over the whole batch, pages and output resident in HBM.
+The RLE_DICTIONARY config (configs[0]: 16 Mi int64, 64 Ki-entry dictionary, 64 pages of 262144)
+is timed beside it and reported under "extra".
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+With N > 1 every rank decodes its own row groups (row group g -> GPU g mod N, no collective on
+the data path); per-GPU work is fixed, so scaling is weak.  Rank 0 prints one JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (spec)
+
+
+# --------------------------------------------------------------------------- input generation
+# Page bytes are produced here with numpy (the layout parquet-go's writer emits:
+# encoding/delta/binary_packed.go:123-181, encoding/rle/dictionary.go:23-28); the checker under
+# oracle/ is used only by the cpu_baseline leg below.
+
+def _uvarint(v: int) -> bytes:
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+def _zigzag(v: int) -> int:
+    return (v << 1) ^ (v >> 63) if v >= 0 else (((-v) << 1) - 1)
+
+
+def _pack_rows(vals: np.ndarray, w: int) -> np.ndarray:
+    """vals: (M, 32) uint64, all < 2**w -> (M, 4*w) bytes, fields LSB first."""
+    if w == 0:
+        return np.zeros((vals.shape[0], 0), np.uint8)
+    bits = np.unpackbits(vals.astype("<u8").view(np.uint8).reshape(vals.shape[0], 32, 8), axis=2, bitorder="little")
+    bits = bits[:, :, :w].reshape(vals.shape[0], 32 * w)
+    return np.packbits(bits, axis=1, bitorder="little")
+
+
+def delta_page_int64(values: np.ndarray) -> bytes:
+    """DELTA_BINARY_PACKED page, block 128 / 4 miniblocks, as the reference writer lays it out."""
+    n = values.size
+    head = _uvarint(128) + _uvarint(4) + _uvarint(n) + _uvarint(_zigzag(int(values[0])) if n else 0)
+    if n < 2:
+        return head
+    d = np.diff(values.astype(np.int64))
+    nblocks = (d.size + 127) // 128
+    pad = nblocks * 128 - d.size
+    # the writer deltas over a zero padded block and takes the minimum over all 128 slots
+    if pad:
+        tail = np.zeros(pad, np.int64)
+        tail[0] = -int(values[-1])
+        d = np.concatenate([d, tail])
+    blocks = d.reshape(nblocks, 128)
+    mins = blocks.min(axis=1)
+    rel = (blocks - mins[:, None]).astype(np.uint64)
+    if pad:
+        rel[-1, 128 - pad:] = 0
+    mb = rel.reshape(nblocks * 4, 32)
+    mx = mb.max(axis=1)
+    widths = np.zeros(mb.shape[0], np.uint8)
+    nz = mx > 0
+    widths[nz] = np.floor(np.log2(mx[nz].astype(np.float64))).astype(np.uint8) + 1
+    # float log2 can be off by one at powers of two of large values: fix up exactly
+    for k in np.nonzero(nz)[0]:
+        widths[k] = int(mx[k]).bit_length()
+    packed = [None] * mb.shape[0]
+    for w in np.unique(widths):
+        sel = np.nonzero(widths == w)[0]
+        rows = _pack_rows(mb[sel], int(w))
+        for r, k in zip(rows, sel):
+            packed[k] = r.tobytes()
+    out = bytearray(head)
+    for b in range(nblocks):
+        out += _uvarint(_zigzag(int(mins[b])))
+        out += widths[4 * b: 4 * b + 4].tobytes()
+        for m in range(4):
+            out += packed[4 * b + m]
+    return bytes(out)
+
+
+def rle_dict_page(indexes: np.ndarray) -> bytes:
+    """RLE_DICTIONARY index page of uniformly random indexes: width byte + one bit-packed run
+    (random 16-bit indexes never give the writer eight equal values in a row to run-length)."""
+    bw = int(indexes.max()).bit_length()
+    assert indexes.size % 8 == 0 and bw == 16
+    return bytes([bw]) + _uvarint(((indexes.size // 8) << 1) | 1) + indexes.astype("<u2").tobytes()
+
+
+def splitmix64(seed: int):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+# --------------------------------------------------------------------------- workloads
+
+class Workload:
+    """Pages resident in HBM + a prepared pqd batch."""
+
+    def __init__(self, pkg, ctx, device, enc_pages, replicate, kind, encoding, values_per_page, dictionary=None):
+        import torch
+        self.torch = torch
+        self.pkg = pkg
+        dev = f"cuda:{device}"
+        uniq = len(enc_pages)
+        # one contiguous HBM region of page slots, 256-byte aligned starts
+        slot = max((len(p) + 255) // 256 * 256 for p in enc_pages)
+        self.n_pages = uniq * replicate
+        self.src = torch.zeros(self.n_pages * slot + 256, dtype=torch.uint8, device=dev)
+        host = np.zeros(uniq * slot, np.uint8)
+        for k, p in enumerate(enc_pages):
+            host[k * slot: k * slot + len(p)] = np.frombuffer(p, np.uint8)
+        first = torch.from_numpy(host).to(dev)
+        for r in range(replicate):
+            self.src[r * uniq * slot: (r + 1) * uniq * slot].copy_(first)
+        del first
+        elem = 8
+        self.values = self.n_pages * values_per_page
+        self.dst = torch.empty(self.values * elem // 8, dtype=torch.int64, device=dev)
+        self.dict_t = None
+        if dictionary is not None:
+            self.dict_t = torch.from_numpy(dictionary.copy()).to(dev)
+        pages = []
+        enc_bytes = 0
+        for i in range(self.n_pages):
+            p = pkg.Page()
+            plen = len(enc_pages[i % uniq])
+            p.src, p.src_len = self.src.data_ptr() + i * slot, plen
+            p.dst, p.dst_cap = self.dst.data_ptr() + i * values_per_page * elem, values_per_page * elem
+            p.num_values = values_per_page
+            p.encoding, p.kind = encoding, kind
+            if dictionary is not None:
+                p.dict, p.dict_len = self.dict_t.data_ptr(), dictionary.size
+            pages.append(p)
+            enc_bytes += plen
+        self.encoded_bytes = enc_bytes
+        self.decoded_bytes = self.values * elem
+        self.dict_bytes = 0 if dictionary is None else dictionary.nbytes
+        self.batch = pkg.Batch(ctx, pages)
+        self.values_per_page = values_per_page
+
+    @property
+    def algorithmic_bytes(self):
+        return self.encoded_bytes + self.decoded_bytes + self.dict_bytes
+
+    def launch(self, stream):
+        self.batch.launch(stream)
+
+    def check(self, stream):
+        res = self.batch.finish(stream)
+        bad = [(i, res[i].status) for i in range(self.n_pages) if res[i].status != 0]
+        if bad:
+            raise RuntimeError(f"decode failed on {len(bad)} pages, first {bad[0]}")
+
+
+def build_delta_workload(pkg, ctx, device, seed, n_pages, values_per_page, unique):
+    rng = splitmix64(0xC2 + seed)
+    enc, expect = [], []
+    t0 = 1_600_000_000_000_000_000
+    for k in range(unique):
+        deltas = rng.integers(1_000_000, 1_000_000 + 4096, size=values_per_page, dtype=np.int64)
+        ts = t0 + np.cumsum(deltas)
+        t0 = int(ts[-1])
+        enc.append(delta_page_int64(ts))
+        expect.append(ts)
+    wl = Workload(pkg, ctx, device, enc, n_pages // unique, pkg.KIND.INT64, pkg.ENC.DELTA_BINARY_PACKED, values_per_page)
+    wl.expect, wl.enc_pages = expect, enc
+    return wl
+
+
+def build_rle_dict_workload(pkg, ctx, device, seed, n_pages, values_per_page, dict_size):
+    rng = splitmix64(0xC1 + seed)
+    dictionary = rng.integers(-2**62, 2**62, size=dict_size, dtype=np.int64)
+    enc, expect = [], []
+    for k in range(n_pages):
+        idx = rng.integers(0, dict_size, size=values_per_page, dtype=np.int64).astype(np.int32)
+        enc.append(rle_dict_page(idx))
+        expect.append(idx)
+    wl = Workload(pkg, ctx, device, enc, 1, pkg.KIND.INT64, pkg.ENC.RLE_DICTIONARY, values_per_page, dictionary)
+    wl.expect_idx, wl.dictionary, wl.enc_pages = expect, dictionary, enc
+    return wl
+
+
+def time_steps(torch, wl, stream, steps, warmup, dist=None):
+    for _ in range(warmup):
+        wl.launch(stream)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        wl.launch(stream)
+        b.record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    return wall, kernel_ms
+
+
+def cpu_baseline(wl, budget_s=12.0):
+    """The CPU restatement of the reference decoder (oracle/, kind "port"), one host core, on a
+    bounded sample of the same pages."""
+    from oracle import pqoracle as O
+    L = O.lib()
+    pages = wl.enc_pages[: min(len(wl.enc_pages), 16)]
+    srcs = [np.frombuffer(p, np.uint8) for p in pages]
+    dst = np.zeros(wl.values_per_page, np.int64)
+    done_bytes, reps = 0, 0
+    t0 = time.perf_counter()
+    while True:
+        for s in srcs:
+            r = L.pqo_delta_decode_int64(dst.ctypes.data, dst.nbytes, s.ctypes.data, s.size)
+            assert r.status == 0
+            done_bytes += dst.nbytes
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s:
+            break
+    return {"value": round(done_bytes / el / 1e9, 3), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": f"{len(srcs)} of the workload's pages ({wl.values_per_page} values each) decoded {reps}x by "
+                      f"oracle/pq_oracle.c (scalar restatement of encoding/delta/binary_packed.go) in {el:.1f} s on one host core"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pages", type=int, default=2048)
+    ap.add_argument("--values-per-page", type=int, default=131072)
+    ap.add_argument("--unique-pages", type=int, default=64, help="distinct seeded pages generated on the host; tiled in HBM to --pages")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--skip-check", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import __graft_entry__ as entry
+    pkg = entry.load_package()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist_mod.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        dist = dist_mod
+    device = local_rank if world > 1 else 0
+    torch.cuda.set_device(device)
+    ctx = pkg.Context(device)
+    stream = torch.cuda.current_stream(device).cuda_stream
+
+    unique = min(args.unique_pages, args.pages)
+    while args.pages % unique:
+        unique -= 1
+    wl = build_delta_workload(pkg, ctx, device, rank, args.pages, args.values_per_page, unique)
+
+    # correctness of what is being timed: every distinct page and its last replica
+    wl.launch(stream)
+    wl.check(stream)
+    if not args.skip_check:
+        out = wl.dst.view(wl.n_pages, wl.values_per_page)
+        for k in range(unique):
+            for slot in (k, wl.n_pages - unique + k):
+                got = out[slot].cpu().numpy()
+                if not np.array_equal(got, wl.expect[k]):
+                    raise RuntimeError(f"page {slot} decoded wrong")
+
+    wall, kernel_ms = time_steps(torch, wl, stream, args.steps, args.warmup, dist)
+    t = torch.tensor([wall], dtype=torch.float64, device=f"cuda:{device}")
+    if dist is not None:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    wall_max = float(t.item())
+    ms_per_step = wall_max / args.steps * 1e3
+    decoded_gb = wl.decoded_bytes * world / 1e9
+    value = decoded_gb / (wall_max / args.steps)
+    avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
+    achieved = wl.algorithmic_bytes / avg_kernel_s / 1e9
+
+    result = {
+        "metric": "device-resident decoded GB/s (DELTA_BINARY_PACKED int64 pages)",
+        "value": round(value, 1),
+        "unit": "GB/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int64",
+        "data": f"synthetic: {unique} distinct seeded timestamp pages tiled in HBM to {wl.n_pages} page slots per GPU, "
+                "deltas 1e6 + U[0,4096) ns (miniblock width 12), uncompressed",
+        "config": {"workload": f"DELTA_BINARY_PACKED int64, {wl.values} values per GPU in {wl.n_pages} pages of "
+                               f"{wl.values_per_page}, blocks of 128 / 4 miniblocks (BASELINE.json configs[1])",
+                   "parallelism": f"row groups sharded over {world} GPU(s), no data-path collective"},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _traffic("delta"),
+                     "kernel": "delta_decode_kernel<uint64_t>", "kernel_ms": round(avg_kernel_s * 1e3, 4),
+                     "algorithmic_bytes": wl.algorithmic_bytes},
+    }
+
+    if rank == 0 and not args.no_extra:
+        # RLE_DICTIONARY config, timed the same way (not part of `value`)
+        del wl.batch
+        wl_src, wl_dst = wl.src, wl.dst
+        c1 = build_rle_dict_workload(pkg, ctx, device, rank, 64, 262144, 65536)
+        c1.launch(stream)
+        c1.check(stream)
+        if not args.skip_check:
+            out = c1.dst.view(c1.n_pages, c1.values_per_page)
+            for k in (0, c1.n_pages - 1):
+                if not np.array_equal(out[k].cpu().numpy(), c1.dictionary[c1.expect_idx[k]]):
+                    raise RuntimeError("RLE_DICTIONARY page decoded wrong")
+        w1, k1 = time_steps(torch, c1, stream, max(args.steps, 20), args.warmup, None)
+        s1 = w1 / max(args.steps, 20)
+        a1 = c1.algorithmic_bytes / (float(np.mean(k1)) / 1e3) / 1e9
+        result["extra"] = {"rle_dictionary_int64": {
+            "workload": "RLE_DICTIONARY int64, 16 Mi values, 64 Ki-entry dictionary, 64 pages of 262144, index width 16 (BASELINE.json configs[0])",
+            "decoded_GBps": round(c1.decoded_bytes / s1 / 1e9, 1), "ms_per_step": round(s1 * 1e3, 4),
+            "kernels_ms": round(float(np.mean(k1)), 4),
+            "roofline": {"bound": "hbm", "achieved": round(a1, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(a1 / HBM_PEAK_GBS, 4), "traffic": _traffic("rle_dict"),
+                         "algorithmic_bytes": c1.algorithmic_bytes}}}
+        del wl_src, wl_dst
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result["cpu_baseline"] = cpu_baseline(wl)
+    elif rank == 0:
+        result["cpu_baseline"] = None
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+def _traffic(which):
+    """HBM bytes per launch from the committed rocprofv3 --pmc summary, if one exists."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(path)).get(which)
+    except Exception:
+        return None
+
+
+if __name__ == "__main__":
+    main()

@@ -113,6 +113,55 @@ template <typename U> struct Elem;
 template <> struct Elem<uint32_t> { static constexpr uint32_t max_bw = 32; };
 template <> struct Elem<uint64_t> { static constexpr uint32_t max_bw = 64; };
 
+// Page header (binary_packed.go:409-452) read by one lane out of the ring; fills
+// the control block, writes the first value and reports block geometry.
+template <typename U>
+__device__ inline void parse_header(const uint8_t* ring8, uint64_t mis, uint64_t end, uint64_t dst_cap, U* out, Ctl& c,
+                                    int64_t& block_size, int64_t& num_mb) {
+    c.status = PQD_OK; c.arg = 0; c.stop = 0; c.count = 0; c.total = 0; c.first = 0; c.vpm = 0; c.slot_base = 0;
+    uint64_t p = mis, u[3] = {0, 0, 0};
+    for (int f = 0; f < 3 && c.status == PQD_OK; f++) {
+        int k = ring_uvarint(ring8, p, end, &u[f]);
+        if (k == 0) { c.status = PQD_ERR_UNEXPECTED_EOF; c.arg = PQD_EOF_DELTA_HEADER; }
+        else if (k < 0) { c.status = PQD_ERR_VARINT_OVERFLOW; c.arg = (int64_t)(p - mis); }
+        else p += k;
+    }
+    if (c.status == PQD_OK) {
+        uint64_t z;
+        int k = ring_uvarint(ring8, p, end, &z);
+        if (k == 0) { c.status = PQD_ERR_UNEXPECTED_EOF; c.arg = PQD_EOF_DELTA_HEADER; }
+        else if (k < 0) { c.status = PQD_ERR_VARINT_OVERFLOW; c.arg = (int64_t)(p - mis); }
+        else { p += k; c.first = unzigzag(z); }
+    }
+    block_size = (int64_t)u[0];
+    num_mb = (int64_t)u[1];
+    const int64_t total = (int64_t)u[2];
+    if (c.status == PQD_OK) {
+        // binary_packed.go:437-449, in the reference's order
+        if (num_mb == 0) { c.status = PQD_ERR_BAD_DELTA_HEADER; c.arg = PQD_DELTA_BAD_NUM_MINIBLOCKS; }
+        else if (block_size <= 0 || (block_size % 128) != 0) { c.status = PQD_ERR_BAD_DELTA_HEADER; c.arg = PQD_DELTA_BAD_BLOCK_SIZE; }
+        else if (block_size > 65536) { c.status = PQD_ERR_BAD_DELTA_HEADER; c.arg = PQD_DELTA_BLOCK_TOO_LARGE; }
+        else if (num_mb <= 0 || ((block_size / num_mb) % 32) != 0) { c.status = PQD_ERR_BAD_DELTA_HEADER; c.arg = PQD_DELTA_BAD_MINIBLOCK_SIZE; }
+        else if (total < 0) { c.status = PQD_ERR_BAD_DELTA_HEADER; c.arg = PQD_DELTA_NEGATIVE_TOTAL; }
+        else if (total > 2147483647LL) { c.status = PQD_ERR_BAD_DELTA_HEADER; c.arg = PQD_DELTA_TOO_MANY_VALUES; }
+    }
+    c.consumed = p;
+    if (c.status == PQD_OK && total > 0) {
+        if (sizeof(U) == 4 && (c.first < -2147483647LL - 1 || c.first > 2147483647LL)) {
+            c.status = PQD_ERR_FIRST_VALUE_RANGE; c.arg = c.first;
+        } else if ((uint64_t)total * sizeof(U) > dst_cap) {
+            c.status = PQD_ERR_DST_TOO_SMALL; c.arg = (int64_t)((uint64_t)total * sizeof(U));
+        }
+    }
+    if (c.status == PQD_OK) {
+        c.total = (uint64_t)total;
+        c.vpm = (uint32_t)(block_size / num_mb);
+        if (total > 0) out[0] = (U)c.first;
+    }
+    if (c.status != PQD_OK || total <= 1) c.stop = 1;
+    c.lo = p;
+}
+
 // State of the header walk, kept in lane 0's registers across tiles.
 struct Walk {
     uint64_t pos;       // ring-space offset of the next unread byte
@@ -126,6 +175,270 @@ struct Walk {
     uint32_t mb_in_block, nbw_in_block;
     uint32_t mb_global; // miniblocks started so far
 };
+
+// Unpacks, prefix-sums and stores one tile: thread t owns deltas 4t..4t+3 of the
+// tile, which sit in miniblock `slot` starting at field `within`.  Adds the
+// tile's sum to `carry`.  Contains one workgroup barrier.
+template <typename U>
+__device__ inline void decode_tile(Shared& sh, U* out, uint64_t done, uint32_t count, uint32_t slot, uint32_t within,
+                                   U& carry) {
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63, wave = tid >> 6;
+    // ---- unpack 4 consecutive deltas per thread ----
+    const uint32_t j = tid * 4;
+    U v[4] = {0, 0, 0, 0};
+    if (j < count) {
+            const Slot s = sh.slots[slot];
+            const uint32_t bw = s.bw;
+            const U md = (U)s.min_delta;
+            uint64_t bit0 = (uint64_t)within * bw;
+            uint64_t byte0 = s.off + (bit0 >> 3);
+            uint32_t dw = (uint32_t)((byte0 & RING_MASK) >> 2);
+            uint32_t sft = (uint32_t)((byte0 & 3) * 8 + (bit0 & 7));
+            const U mask = bw >= Elem<U>::max_bw ? ~(U)0 : (((U)1 << bw) - 1);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                uint32_t b = sft + i * bw;
+                uint32_t k = (dw + (b >> 5)) & RING_DW_MASK;
+                uint32_t sh_ = b & 31;
+                uint64_t w01 = (uint64_t)sh.ring[k] | ((uint64_t)sh.ring[(k + 1) & RING_DW_MASK] << 32);
+                uint64_t f = w01 >> sh_;
+                if (sizeof(U) == 8) {
+                    uint64_t w2 = sh.ring[(k + 2) & RING_DW_MASK];
+                    if (sh_) f |= w2 << (64 - sh_);
+                }
+                U d = ((U)f & mask) + md;
+                v[i] = (j + i < count) ? d : (U)0;
+            }
+        }
+        // thread-local inclusive scan
+        v[1] += v[0]; v[2] += v[1]; v[3] += v[2];
+        // wave inclusive scan of the thread totals
+        U x = v[3];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            U y = __shfl_up(x, d);
+            if ((int)lane >= d) x += y;
+        }
+        if (lane == 63) sh.wtot[wave] = (uint64_t)x;
+        __syncthreads(); // B3: wave totals visible
+        U wave_prefix = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < DT / 64; w++) {
+            U t = (U)sh.wtot[w];
+            if (w < (int)wave) wave_prefix += t;
+            all += t;
+        }
+        U excl = carry + wave_prefix + (x - v[3]);
+        if (j < count) {
+            U* o = out + 1 + done + j;
+            if (j + 4 <= count) {
+                if (sizeof(U) == 8) {
+                    // two 16-byte stores; the array starts one element in, so 8-byte aligned only
+                    uint64_t* o64 = reinterpret_cast<uint64_t*>(o);
+                    ulonglong2 a, b2;
+                    a.x = (uint64_t)(excl + v[0]); a.y = (uint64_t)(excl + v[1]);
+                    b2.x = (uint64_t)(excl + v[2]); b2.y = (uint64_t)(excl + v[3]);
+                    __builtin_memcpy(o64, &a, 16);
+                    __builtin_memcpy(o64 + 2, &b2, 16);
+                } else {
+                    uint4 a;
+                    a.x = (uint32_t)(excl + v[0]); a.y = (uint32_t)(excl + v[1]);
+                    a.z = (uint32_t)(excl + v[2]); a.w = (uint32_t)(excl + v[3]);
+                    __builtin_memcpy(o, &a, 16);
+                }
+            } else {
+                for (uint32_t i = 0; i < 4 && j + i < count; i++) o[i] = excl + v[i];
+            }
+        }
+    carry += all;
+}
+
+
+// ---------------------------------------------------------------------------
+// Fast path: block sizes 128/256/512/1024 with at most 32 miniblocks (every
+// writer in practice; the reference writes 128/4).  A tile is then a whole
+// number of blocks, and wave 0 finds the tile's block headers in parallel:
+// lane l guesses that block l starts l * S bytes after the first one, S being
+// the size of the block before, parses the header it finds there and the
+// guess holds for every lane whose predecessors all measured S again.  With
+// steady widths one round finds all blocks of a tile; when every block differs
+// the walk degrades to one block per round, still all in LDS.
+// Pages of any other geometry are left to the general kernel below.
+// ---------------------------------------------------------------------------
+
+constexpr uint64_t FAST_DONE = 0x46415354444f4e45ull; // marks a result the fast kernel produced
+
+template <typename U>
+__global__ __launch_bounds__(DT) void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                       const uint32_t* __restrict__ items) {
+    __shared__ Shared sh;
+    const uint32_t item = items[blockIdx.x];
+    const DevPage& pg = pages[item];
+    DevResult* res = &results[item];
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63;
+    const uint8_t* ring8 = reinterpret_cast<const uint8_t*>(sh.ring);
+
+    uint64_t src_skip = 0;
+    if (pg.chain >= 0) src_skip = results[pg.chain].consumed;
+    const uint8_t* src = pg.src + src_skip;
+    const uint64_t src_len = pg.src_len > src_skip ? pg.src_len - src_skip : 0;
+    const uint64_t mis = reinterpret_cast<uintptr_t>(src) & 15;
+    const uint8_t* base = src - mis;
+    const uint64_t end = mis + src_len;
+    U* out = reinterpret_cast<U*>(pg.dst);
+
+    uint64_t c_next = 0;
+    ring_fill(sh.ring, base, end, mis, c_next);
+    __syncthreads();
+
+    if (tid == 0) {
+        Ctl c;
+        int64_t block_size = 0, num_mb = 0;
+        parse_header<U>(ring8, mis, end, pg.dst_cap, out, c, block_size, num_mb);
+        const bool regular = c.status != PQD_OK || c.total <= 1 ||
+                             ((block_size == 128 || block_size == 256 || block_size == 512 || block_size == 1024) && num_mb <= 32);
+        // slot_base carries the verdict and the geometry to the other lanes
+        c.slot_base = regular ? (uint32_t)num_mb : 0xffffffffu;
+        c.count = (uint32_t)block_size;
+        sh.ctl = c;
+    }
+    __syncthreads();
+    if (sh.ctl.slot_base == 0xffffffffu) { // irregular geometry: the general kernel decodes this page
+        if (tid == 0) res->aux = 0;
+        return;
+    }
+
+    const uint64_t total = sh.ctl.total;
+    const uint32_t vpm = sh.ctl.vpm;
+    const uint32_t nmb = sh.ctl.slot_base;
+    const uint32_t block_size = sh.ctl.count;
+    const uint32_t vpm_shift = vpm ? 31 - __clz(vpm) : 0;
+    const uint32_t blk_shift = block_size ? 31 - __clz(block_size) : 0;
+    int stop = sh.ctl.stop;
+    U carry = (U)sh.ctl.first;
+    uint64_t done = 0;
+    const uint64_t n_deltas = total > 0 ? total - 1 : 0;
+    // wave 0 only: start of the next block and the size guess
+    uint64_t pos = sh.ctl.lo;
+    uint32_t guess = 0;
+    __syncthreads();
+
+    while (!stop) {
+        ring_fill(sh.ring, base, end, sh.ctl.lo, c_next);
+        __syncthreads(); // B1
+
+        const uint32_t want = (uint32_t)(n_deltas - done < TILE ? n_deltas - done : TILE);
+        if (tid < 64) {
+            const uint32_t nb_want = (want + block_size - 1) >> blk_shift;
+            uint32_t found = 0, got = 0;
+            int32_t status = PQD_OK;
+            int64_t arg = 0;
+            while (found < nb_want) {
+                const bool active = lane < nb_want - found;
+                const uint64_t cand = pos + (uint64_t)lane * guess;
+                // values this block still has to deliver, and the miniblocks that hold them
+                const uint32_t bidx = found + lane;
+                const uint32_t bvals = active ? (want - (bidx << blk_shift) < block_size ? want - (bidx << blk_shift) : block_size) : 0;
+                const uint32_t need_mb = (bvals + vpm - 1) >> vpm_shift;
+                int32_t err = PQD_OK;
+                int64_t err_arg = 0;
+                bool at_end = false;
+                uint32_t size = 0, have_mb = 0;
+                if (active) {
+                    if (cand >= end) {
+                        at_end = true;
+                    } else {
+                        uint64_t z;
+                        int k = ring_uvarint(ring8, cand, end, &z);
+                        if (k == 0) { err = PQD_ERR_UNEXPECTED_EOF; err_arg = PQD_EOF_DELTA_MIN_DELTA; }
+                        else if (k < 0) { err = PQD_ERR_VARINT_OVERFLOW; err_arg = (int64_t)(cand - mis); }
+                        else {
+                            const int64_t md = unzigzag(z);
+                            const uint64_t wpos = cand + k;
+                            const uint32_t nbw = end - wpos < nmb ? (uint32_t)(end - wpos) : nmb;
+                            uint64_t off = wpos + nbw;
+                            have_mb = nbw < need_mb ? nbw : need_mb;
+                            for (uint32_t m = 0; m < have_mb; m++) {
+                                const uint32_t bw = ring8[(wpos + m) & RING_MASK];
+                                if (bw > Elem<U>::max_bw) { err = PQD_ERR_INVALID_BIT_WIDTH; err_arg = bw; have_mb = m; break; }
+                                Slot sl;
+                                sl.min_delta = md; sl.off = off; sl.bw = bw; sl.pad = 0;
+                                sh.slots[(bidx << (blk_shift - vpm_shift)) + m] = sl;
+                                off += ((uint64_t)vpm * bw) >> 3;
+                            }
+                            size = (uint32_t)(off - cand);
+                        }
+                    }
+                }
+                const bool bad = err != PQD_OK || at_end;
+                const bool ok = active && !bad && size == guess;
+                const unsigned long long okmask = __ballot(ok);
+                const unsigned long long badmask = __ballot(active && bad);
+                uint32_t lead = okmask == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~okmask);
+                uint32_t valid = lead + 1 < nb_want - found ? lead + 1 : nb_want - found;
+                if ((badmask >> (valid - 1)) & 1) {
+                    if (valid == 1) { // the block the stream really continues with is unreadable
+                        const int32_t e0 = __shfl(err, 0);
+                        const int64_t a0 = __shfl(err_arg, 0);
+                        if (e0 != PQD_OK) { status = e0; arg = a0; }
+                        else { status = PQD_ERR_MISSING_VALUES; arg = (int64_t)(n_deltas - done - got); }
+                        break;
+                    }
+                    valid--; // report it when it is first in line
+                }
+                const uint32_t last = valid - 1;
+                const uint32_t last_have = __shfl(have_mb, last);
+                const uint32_t last_need = __shfl(need_mb, last);
+                const uint32_t last_vals = __shfl(bvals, last);
+                const uint32_t last_size = __shfl(size, last);
+                const uint64_t last_cand = __shfl(cand, last);
+                found += valid;
+                got = ((found - 1) << blk_shift) + (last_have < last_need ? last_have << vpm_shift : last_vals);
+                pos = last_cand + last_size;
+                guess = last_size;
+                if (last_have < last_need) { // the widths ran out: nothing follows this block
+                    status = PQD_ERR_MISSING_VALUES;
+                    arg = (int64_t)(n_deltas - done - got);
+                    break;
+                }
+            }
+            if (tid == 0) {
+                Ctl& c = sh.ctl;
+                c.count = got;
+                c.lo = pos;
+                c.consumed = pos < end ? pos : end;
+                if (status != PQD_OK) { c.status = status; c.arg = arg; }
+                if (status != PQD_OK || done + got >= n_deltas) c.stop = 1;
+            }
+        }
+        __syncthreads(); // B2
+
+        const uint32_t count = sh.ctl.count;
+        stop = sh.ctl.stop;
+        const uint32_t j = tid * 4;
+        decode_tile<U>(sh, out, done, count, j >> vpm_shift, j & (vpm - 1), carry);
+        done += count;
+    }
+
+    __syncthreads();
+    const int32_t status = sh.ctl.status;
+    if (status == PQD_ERR_MISSING_VALUES || status == PQD_ERR_UNEXPECTED_EOF || status == PQD_ERR_VARINT_OVERFLOW ||
+        status == PQD_ERR_INVALID_BIT_WIDTH) {
+        for (uint64_t k = 1 + done + tid; k < total; k += DT) out[k] = 0;
+    }
+    if (tid == 0) {
+        res->status = status;
+        res->arg = sh.ctl.arg;
+        res->total = total;
+        res->out_values = total;
+        res->out_bytes = total * sizeof(U);
+        res->consumed = src_skip + (sh.ctl.consumed - mis);
+        res->n_runs = 0;
+        res->aux = FAST_DONE;
+    }
+}
 
 template <typename U>
 __global__ __launch_bounds__(DT) void delta_decode_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
@@ -147,6 +460,7 @@ __global__ __launch_bounds__(DT) void delta_decode_kernel(const DevPage* __restr
     const uint8_t* base = src - mis;       // ring-space 0
     const uint64_t end = mis + src_len;    // ring-space end of page
     U* out = reinterpret_cast<U*>(pg.dst);
+    if (res->aux == FAST_DONE) return; // uniform: the fast kernel decoded this page
 
     uint64_t c_next = 0;
     ring_fill(sh.ring, base, end, mis, c_next);
@@ -156,48 +470,10 @@ __global__ __launch_bounds__(DT) void delta_decode_kernel(const DevPage* __restr
     uint64_t num_mb_l0 = 0; // lane 0 only: miniblocks per block
     if (tid == 0) {
         Ctl c;
-        c.status = PQD_OK; c.arg = 0; c.stop = 0; c.count = 0; c.total = 0; c.first = 0; c.vpm = 0; c.slot_base = 0;
-        uint64_t p = mis, u[3] = {0, 0, 0};
-        for (int f = 0; f < 3 && c.status == PQD_OK; f++) {
-            int k = ring_uvarint(ring8, p, end, &u[f]);
-            if (k == 0) { c.status = PQD_ERR_UNEXPECTED_EOF; c.arg = PQD_EOF_DELTA_HEADER; }
-            else if (k < 0) { c.status = PQD_ERR_VARINT_OVERFLOW; c.arg = (int64_t)(p - mis); }
-            else p += k;
-        }
-        if (c.status == PQD_OK) {
-            uint64_t z;
-            int k = ring_uvarint(ring8, p, end, &z);
-            if (k == 0) { c.status = PQD_ERR_UNEXPECTED_EOF; c.arg = PQD_EOF_DELTA_HEADER; }
-            else if (k < 0) { c.status = PQD_ERR_VARINT_OVERFLOW; c.arg = (int64_t)(p - mis); }
-            else { p += k; c.first = unzigzag(z); }
-        }
-        int64_t block_size = (int64_t)u[0], num_mb = (int64_t)u[1], total = (int64_t)u[2];
-        if (c.status == PQD_OK) {
-            // binary_packed.go:437-449, in the reference's order
-            if (num_mb == 0) { c.status = PQD_ERR_BAD_DELTA_HEADER; c.arg = PQD_DELTA_BAD_NUM_MINIBLOCKS; }
-            else if (block_size <= 0 || (block_size % 128) != 0) { c.status = PQD_ERR_BAD_DELTA_HEADER; c.arg = PQD_DELTA_BAD_BLOCK_SIZE; }
-            else if (block_size > 65536) { c.status = PQD_ERR_BAD_DELTA_HEADER; c.arg = PQD_DELTA_BLOCK_TOO_LARGE; }
-            else if (num_mb <= 0 || ((block_size / num_mb) % 32) != 0) { c.status = PQD_ERR_BAD_DELTA_HEADER; c.arg = PQD_DELTA_BAD_MINIBLOCK_SIZE; }
-            else if (total < 0) { c.status = PQD_ERR_BAD_DELTA_HEADER; c.arg = PQD_DELTA_NEGATIVE_TOTAL; }
-            else if (total > 2147483647LL) { c.status = PQD_ERR_BAD_DELTA_HEADER; c.arg = PQD_DELTA_TOO_MANY_VALUES; }
-        }
-        c.consumed = p;
-        if (c.status == PQD_OK && total > 0) {
-            if (sizeof(U) == 4 && (c.first < -2147483647LL - 1 || c.first > 2147483647LL)) {
-                c.status = PQD_ERR_FIRST_VALUE_RANGE; c.arg = c.first;
-            } else {
-                if ((uint64_t)total * sizeof(U) > pg.dst_cap) { c.status = PQD_ERR_DST_TOO_SMALL; c.arg = (int64_t)((uint64_t)total * sizeof(U)); }
-            }
-        }
-        if (c.status == PQD_OK) {
-            c.total = (uint64_t)total;
-            c.vpm = (uint32_t)(block_size / num_mb);
-            if (total > 0) out[0] = (U)c.first;
-        }
-        if (c.status != PQD_OK || total <= 1) c.stop = 1;
-        wk.pos = p; wk.end = end; wk.bw_pos = 0; wk.min_delta = 0; wk.cur_off = p; wk.cur_bw = 0; wk.cur_rem = 0;
+        int64_t block_size = 0, num_mb = 0;
+        parse_header<U>(ring8, mis, end, pg.dst_cap, out, c, block_size, num_mb);
+        wk.pos = c.lo; wk.end = end; wk.bw_pos = 0; wk.min_delta = 0; wk.cur_off = c.lo; wk.cur_bw = 0; wk.cur_rem = 0;
         wk.cur_within = 0; wk.mb_in_block = 0; wk.nbw_in_block = 0; wk.mb_global = 0;
-        c.lo = p;
         num_mb_l0 = (uint64_t)num_mb;
         sh.ctl = c;
     }
@@ -295,77 +571,15 @@ __global__ __launch_bounds__(DT) void delta_decode_kernel(const DevPage* __restr
 
         const uint32_t count = sh.ctl.count;
         stop = sh.ctl.stop;
-        // ---- unpack 4 consecutive deltas per thread ----
         const uint32_t j = tid * 4;
-        U v[4] = {0, 0, 0, 0};
+        uint32_t slot = 0, within = 0;
         if (j < count) {
             uint64_t g = done + j;                       // global delta index
             uint32_t mb = (uint32_t)(g / vpm);
-            uint32_t within = (uint32_t)(g - (uint64_t)mb * vpm);
-            const Slot s = sh.slots[mb - sh.ctl.slot_base];
-            const uint32_t bw = s.bw;
-            const U md = (U)s.min_delta;
-            uint64_t bit0 = (uint64_t)within * bw;
-            uint64_t byte0 = s.off + (bit0 >> 3);
-            uint32_t dw = (uint32_t)((byte0 & RING_MASK) >> 2);
-            uint32_t sft = (uint32_t)((byte0 & 3) * 8 + (bit0 & 7));
-            const U mask = bw >= Elem<U>::max_bw ? ~(U)0 : (((U)1 << bw) - 1);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                uint32_t b = sft + i * bw;
-                uint32_t k = (dw + (b >> 5)) & RING_DW_MASK;
-                uint32_t sh_ = b & 31;
-                uint64_t w01 = (uint64_t)sh.ring[k] | ((uint64_t)sh.ring[(k + 1) & RING_DW_MASK] << 32);
-                uint64_t f = w01 >> sh_;
-                if (sizeof(U) == 8) {
-                    uint64_t w2 = sh.ring[(k + 2) & RING_DW_MASK];
-                    if (sh_) f |= w2 << (64 - sh_);
-                }
-                U d = ((U)f & mask) + md;
-                v[i] = (j + i < count) ? d : (U)0;
-            }
+            within = (uint32_t)(g - (uint64_t)mb * vpm);
+            slot = mb - sh.ctl.slot_base;
         }
-        // thread-local inclusive scan
-        v[1] += v[0]; v[2] += v[1]; v[3] += v[2];
-        // wave inclusive scan of the thread totals
-        U x = v[3];
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            U y = __shfl_up(x, d);
-            if ((int)lane >= d) x += y;
-        }
-        if (lane == 63) sh.wtot[wave] = (uint64_t)x;
-        __syncthreads(); // B3: wave totals visible
-        U wave_prefix = 0, all = 0;
-#pragma unroll
-        for (int w = 0; w < DT / 64; w++) {
-            U t = (U)sh.wtot[w];
-            if (w < (int)wave) wave_prefix += t;
-            all += t;
-        }
-        U excl = carry + wave_prefix + (x - v[3]);
-        if (j < count) {
-            U* o = out + 1 + done + j;
-            if (j + 4 <= count) {
-                if (sizeof(U) == 8) {
-                    // two 16-byte stores; the array starts one element in, so 8-byte aligned only
-                    uint64_t* o64 = reinterpret_cast<uint64_t*>(o);
-                    ulonglong2 a, b2;
-                    a.x = (uint64_t)(excl + v[0]); a.y = (uint64_t)(excl + v[1]);
-                    b2.x = (uint64_t)(excl + v[2]); b2.y = (uint64_t)(excl + v[3]);
-                    __builtin_memcpy(o64, &a, 16);
-                    __builtin_memcpy(o64 + 2, &b2, 16);
-                } else {
-                    uint4 a;
-                    a.x = (uint32_t)(excl + v[0]); a.y = (uint32_t)(excl + v[1]);
-                    a.z = (uint32_t)(excl + v[2]); a.w = (uint32_t)(excl + v[3]);
-                    __builtin_memcpy(o, &a, 16);
-                }
-            } else {
-                for (uint32_t i = 0; i < 4 && j + i < count; i++) o[i] = excl + v[i];
-            }
-        }
-        carry += all;
+        decode_tile<U>(sh, out, done, count, slot, within, carry);
         done += count;
     }
 
@@ -395,10 +609,13 @@ __global__ __launch_bounds__(DT) void delta_decode_kernel(const DevPage* __restr
 void launch_delta(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, bool is64,
                   hipStream_t stream) {
     if (n_items == 0) return;
-    if (is64)
+    if (is64) {
+        hipLaunchKernelGGL(delta_fast_kernel<uint64_t>, dim3(n_items), dim3(DT), 0, stream, pages, results, items);
         hipLaunchKernelGGL(delta_decode_kernel<uint64_t>, dim3(n_items), dim3(DT), 0, stream, pages, results, items);
-    else
+    } else {
+        hipLaunchKernelGGL(delta_fast_kernel<uint32_t>, dim3(n_items), dim3(DT), 0, stream, pages, results, items);
         hipLaunchKernelGGL(delta_decode_kernel<uint32_t>, dim3(n_items), dim3(DT), 0, stream, pages, results, items);
+    }
 }
 
 } // namespace pqd
