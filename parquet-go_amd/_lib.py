@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libpqd.so")
+_SO = os.environ.get("PQD_LIBRARY") or os.path.join(_HERE, "libpqd.so")
 
 
 class PqdError(RuntimeError):

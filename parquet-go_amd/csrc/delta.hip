@@ -31,9 +31,8 @@ constexpr int BW_CACHE = 64;                  // bit widths of one block kept in
 
 struct Slot {
     int64_t min_delta;
-    uint64_t off;  // ring-space byte offset of the miniblock data
+    uint32_t off;  // ring-space byte offset of the miniblock data, low 32 bits (only ring positions are derived from it)
     uint32_t bw;
-    uint32_t pad;
 };
 
 struct Ctl {
@@ -50,7 +49,7 @@ struct Ctl {
 };
 
 struct Shared {
-    uint32_t ring[RING_BYTES / 4];
+    uint32_t ring[RING_BYTES / 4 + 4]; // + mirror of the first 16 bytes, so a field never wraps
     Slot slots[MAX_SLOTS];
     uint64_t wtot[DT / 64];
     Ctl ctl;
@@ -81,30 +80,38 @@ __device__ inline int64_t unzigzag(uint64_t u) {
     return (u & 1) ? ~x : x;
 }
 
+// Writes 16 loaded bytes at ring-space offset v, zeroing what lies at or past
+// `end` (a truncated miniblock is zero padded, binary_packed.go:380-389).  The
+// first 16 bytes of the ring are mirrored behind its end, so a reader may
+// fetch the two dwords after any ring position without wrapping.
+__device__ inline void ring_put(uint32_t* ring, uint64_t v, uint64_t end, u32x4 w) {
+    if (__builtin_expect(v + 16 > end, 0)) {
+        const int64_t keep = (int64_t)end - (int64_t)v; // bytes of w that belong to the page (may be <= 0)
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int64_t kb = keep - 4 * k;
+            const uint32_t m = kb >= 4 ? 0xffffffffu : (kb <= 0 ? 0u : ((1u << ((uint32_t)kb * 8)) - 1));
+            w[k] &= m;
+        }
+    }
+    const uint32_t at = (uint32_t)(v & RING_MASK) >> 2;
+    *reinterpret_cast<u32x4*>(&ring[at]) = w;
+    if (at == 0) *reinterpret_cast<u32x4*>(&ring[RING_BYTES / 4]) = w;
+}
+
 // Brings ring chunks in until [lo, lo + LOOK) is resident.  `base` is the
 // 16-byte aligned address ring-space offset 0 maps to; bytes at or past
 // `end` are stored as zero (a truncated miniblock is zero padded,
 // binary_packed.go:380-389).  Uniform across the workgroup.
-__device__ inline void ring_fill(uint32_t* ring, const uint8_t* base, uint64_t end, uint64_t lo, uint64_t& c_next) {
+__device__ inline void ring_fill(uint32_t* ring, gptr<const uint8_t> base, uint64_t end, uint64_t lo, uint64_t& c_next) {
     uint64_t c_lo = lo / CHUNK;
     if (c_next < c_lo) c_next = c_lo;
     uint64_t c_stop = c_lo + LOOK / CHUNK; // inclusive last chunk needed
     while (c_next <= c_stop) {
         uint64_t v = c_next * CHUNK + threadIdx.x * 16u;
-        uint4 w = make_uint4(0, 0, 0, 0);
-        if (v < end) {
-            w = *reinterpret_cast<const uint4*>(base + v);
-            if (v + 16 > end) { // zero the bytes past the end of the page
-                uint32_t keep = (uint32_t)(end - v);
-                uint32_t* p = reinterpret_cast<uint32_t*>(&w);
-                for (int k = 0; k < 4; k++) {
-                    uint32_t lo_b = k * 4;
-                    if (keep <= lo_b) p[k] = 0;
-                    else if (keep < lo_b + 4) p[k] &= (1u << ((keep - lo_b) * 8)) - 1;
-                }
-            }
-        }
-        *reinterpret_cast<uint4*>(&ring[(v & RING_MASK) >> 2]) = w;
+        u32x4 w = (u32x4)(0u);
+        if (v < end) w = *(gptr<const u32x4>)(base + v);
+        ring_put(ring, v, end, w);
         c_next++;
     }
 }
@@ -116,7 +123,7 @@ template <> struct Elem<uint64_t> { static constexpr uint32_t max_bw = 64; };
 // Page header (binary_packed.go:409-452) read by one lane out of the ring; fills
 // the control block, writes the first value and reports block geometry.
 template <typename U>
-__device__ inline void parse_header(const uint8_t* ring8, uint64_t mis, uint64_t end, uint64_t dst_cap, U* out, Ctl& c,
+__device__ inline void parse_header(const uint8_t* ring8, uint64_t mis, uint64_t end, uint64_t dst_cap, gptr<U> out, Ctl& c,
                                     int64_t& block_size, int64_t& num_mb) {
     c.status = PQD_OK; c.arg = 0; c.stop = 0; c.count = 0; c.total = 0; c.first = 0; c.vpm = 0; c.slot_base = 0;
     uint64_t p = mis, u[3] = {0, 0, 0};
@@ -176,103 +183,252 @@ struct Walk {
     uint32_t mb_global; // miniblocks started so far
 };
 
-// Unpacks, prefix-sums and stores one tile: thread t owns deltas 4t..4t+3 of the
-// tile, which sit in miniblock `slot` starting at field `within`.  Adds the
-// tile's sum to `carry`.  Contains one workgroup barrier.
+// Cross-lane moves of the wave scan, done with DPP (no LDS round trip).  Lanes
+// whose source lies outside the row, or whose row is masked off, read 0.
+template <int CTRL, int ROW_MASK>
+__device__ inline uint32_t dpp0(uint32_t v) {
+    // all rows enabled: bound_ctrl makes out-of-row sources read 0, no `old` value to set up;
+    // masked rows keep `old`, which then has to be 0
+    if (ROW_MASK == 0xf) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, true);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ inline uint64_t dpp0(uint64_t v) {
+    uint32_t lo = dpp0<CTRL, ROW_MASK>((uint32_t)v);
+    uint32_t hi = dpp0<CTRL, ROW_MASK>((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave: Kogge-Stone inside each row
+// of 16 lanes (row_shr 1,2,4,8), then the row totals are passed on with
+// row_bcast:15 (rows 1 and 3) and row_bcast:31 (rows 2 and 3).
 template <typename U>
-__device__ inline void decode_tile(Shared& sh, U* out, uint64_t done, uint32_t count, uint32_t slot, uint32_t within,
-                                   U& carry) {
+__device__ inline U wave_inclusive_scan(U x) {
+    x += dpp0<0x111, 0xf>(x);
+    x += dpp0<0x112, 0xf>(x);
+    x += dpp0<0x114, 0xf>(x);
+    x += dpp0<0x118, 0xf>(x);
+    x += dpp0<0x142, 0xa>(x);
+    x += dpp0<0x143, 0xc>(x);
+    return x;
+}
+
+// Unpacks and prefix-sums one tile: thread t owns deltas 4t..4t+3 of the tile,
+// which sit in the miniblock `s` describes, starting at field `within`; r[]
+// receives its four decoded values.  Adds the tile's sum to `carry`.  Contains
+// one workgroup barrier.
+// Fields are cut out of the ring with 32-bit funnel shifts (v_alignbit_b32); a
+// 64-bit value is assembled from two halves, never shifted as a whole.
+// Barrier for hand-offs through LDS only.  __syncthreads() also waits for every
+// outstanding global store of the wave (vmcnt(0)); the fast kernel never hands
+// global data from wave to wave, so it must not pay for that.
+__device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <typename U, bool LDS_ONLY>
+__device__ inline U tile_values(const uint32_t* ring, uint64_t* wtot, const Slot s, uint32_t count, uint32_t within, U& carry,
+                                U (&r)[4]) {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63, wave = tid >> 6;
-    // ---- unpack 4 consecutive deltas per thread ----
     const uint32_t j = tid * 4;
     U v[4] = {0, 0, 0, 0};
     if (j < count) {
-            const Slot s = sh.slots[slot];
-            const uint32_t bw = s.bw;
-            const U md = (U)s.min_delta;
-            uint64_t bit0 = (uint64_t)within * bw;
-            uint64_t byte0 = s.off + (bit0 >> 3);
-            uint32_t dw = (uint32_t)((byte0 & RING_MASK) >> 2);
-            uint32_t sft = (uint32_t)((byte0 & 3) * 8 + (bit0 & 7));
-            const U mask = bw >= Elem<U>::max_bw ? ~(U)0 : (((U)1 << bw) - 1);
+        const uint32_t bw = s.bw;
+        const U md = (U)s.min_delta;
+        const uint32_t bit0 = within * bw;               // within < 65536, bw <= 64
+        const uint32_t byte0 = s.off + (bit0 >> 3);
+        const uint32_t dw = (byte0 & RING_MASK) >> 2;
+        const uint32_t sft = (byte0 & 3) * 8 + (bit0 & 7);
+        const uint32_t mask_lo = bw >= 32 ? 0xffffffffu : ((1u << bw) - 1);
+        const uint32_t mask_hi = bw <= 32 ? 0u : (bw >= 64 ? 0xffffffffu : ((1u << (bw - 32)) - 1));
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                uint32_t b = sft + i * bw;
-                uint32_t k = (dw + (b >> 5)) & RING_DW_MASK;
-                uint32_t sh_ = b & 31;
-                uint64_t w01 = (uint64_t)sh.ring[k] | ((uint64_t)sh.ring[(k + 1) & RING_DW_MASK] << 32);
-                uint64_t f = w01 >> sh_;
-                if (sizeof(U) == 8) {
-                    uint64_t w2 = sh.ring[(k + 2) & RING_DW_MASK];
-                    if (sh_) f |= w2 << (64 - sh_);
-                }
-                U d = ((U)f & mask) + md;
-                v[i] = (j + i < count) ? d : (U)0;
-            }
-        }
-        // thread-local inclusive scan
-        v[1] += v[0]; v[2] += v[1]; v[3] += v[2];
-        // wave inclusive scan of the thread totals
-        U x = v[3];
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            U y = __shfl_up(x, d);
-            if ((int)lane >= d) x += y;
-        }
-        if (lane == 63) sh.wtot[wave] = (uint64_t)x;
-        __syncthreads(); // B3: wave totals visible
-        U wave_prefix = 0, all = 0;
-#pragma unroll
-        for (int w = 0; w < DT / 64; w++) {
-            U t = (U)sh.wtot[w];
-            if (w < (int)wave) wave_prefix += t;
-            all += t;
-        }
-        U excl = carry + wave_prefix + (x - v[3]);
-        if (j < count) {
-            U* o = out + 1 + done + j;
-            if (j + 4 <= count) {
-                if (sizeof(U) == 8) {
-                    // two 16-byte stores; the array starts one element in, so 8-byte aligned only
-                    uint64_t* o64 = reinterpret_cast<uint64_t*>(o);
-                    ulonglong2 a, b2;
-                    a.x = (uint64_t)(excl + v[0]); a.y = (uint64_t)(excl + v[1]);
-                    b2.x = (uint64_t)(excl + v[2]); b2.y = (uint64_t)(excl + v[3]);
-                    __builtin_memcpy(o64, &a, 16);
-                    __builtin_memcpy(o64 + 2, &b2, 16);
-                } else {
-                    uint4 a;
-                    a.x = (uint32_t)(excl + v[0]); a.y = (uint32_t)(excl + v[1]);
-                    a.z = (uint32_t)(excl + v[2]); a.w = (uint32_t)(excl + v[3]);
-                    __builtin_memcpy(o, &a, 16);
-                }
+        for (int i = 0; i < 4; i++) {
+            const uint32_t b = sft + i * bw;
+            const uint32_t* q = ring + ((dw + (b >> 5)) & RING_DW_MASK); // q[1], q[2] exist thanks to the mirror
+            const uint32_t w0 = q[0], w1 = q[1];
+            const uint32_t f_lo = __builtin_amdgcn_alignbit(w1, w0, b) & mask_lo; // the shift uses b mod 32
+            U d;
+            if (sizeof(U) == 8) {
+                const uint32_t w2 = q[2];
+                const uint32_t f_hi = __builtin_amdgcn_alignbit(w2, w1, b) & mask_hi;
+                d = (U)(((uint64_t)f_hi << 32) | f_lo);
             } else {
-                for (uint32_t i = 0; i < 4 && j + i < count; i++) o[i] = excl + v[i];
+                d = (U)f_lo;
             }
+            d += md;
+            v[i] = (j + i < count) ? d : (U)0;
         }
+    }
+    // thread-local inclusive scan, then across the wave
+    v[1] += v[0]; v[2] += v[1]; v[3] += v[2];
+    const U x = wave_inclusive_scan<U>(v[3]);
+    if (lane == 63) wtot[wave] = (uint64_t)x;
+    if (LDS_ONLY) lds_barrier(); else __syncthreads(); // B3: wave totals visible
+    U wave_prefix = 0, all = 0;
+#pragma unroll
+    for (int w = 0; w < DT / 64; w++) {
+        const U t = (U)wtot[w];
+        if (w < (int)wave) wave_prefix += t;
+        all += t;
+    }
+    const U excl = carry + wave_prefix + (x - v[3]);
+    r[0] = excl + v[0]; r[1] = excl + v[1]; r[2] = excl + v[2]; r[3] = excl + v[3];
     carry += all;
+    return excl; // the value just before r[0]
 }
 
+// Stores the four values of this thread: 32 contiguous bytes (16 for INT32).
+template <typename U>
+__device__ inline void tile_store(gptr<U> out, uint64_t done, uint32_t count, const U (&r)[4]) {
+    const uint32_t j = threadIdx.x * 4;
+    if (j < count) {
+        // tile base kept scalar (one SGPR pair, advanced per tile) + a small per-thread
+        // offset, instead of a 64-bit per-thread pointer living in VGPRs across the loop
+        const uint64_t ot = (uint64_t)(uintptr_t)out + (1 + done) * sizeof(U);
+        const uint32_t ot_lo = __builtin_amdgcn_readfirstlane((uint32_t)ot);
+        const uint32_t ot_hi = __builtin_amdgcn_readfirstlane((uint32_t)(ot >> 32));
+        gptr<U> o = (gptr<U>)(((uint64_t)ot_hi << 32) | ot_lo) + j;
+        if (j + 4 <= count) {
+            if (sizeof(U) == 8) {
+                // two 16-byte stores; the array starts one element in, so 8-byte aligned only
+                u64x2_a8 a, b2;
+                a.x = (uint64_t)r[0]; a.y = (uint64_t)r[1];
+                b2.x = (uint64_t)r[2]; b2.y = (uint64_t)r[3];
+                *(gptr<u64x2_a8>)(o) = a;
+                *(gptr<u64x2_a8>)(o + 2) = b2;
+            } else {
+                u32x4_a4 a;
+                a.x = (uint32_t)r[0]; a.y = (uint32_t)r[1];
+                a.z = (uint32_t)r[2]; a.w = (uint32_t)r[3];
+                *(gptr<u32x4_a4>)(o) = a;
+            }
+        } else {
+            for (uint32_t i = 0; i < 4 && j + i < count; i++) o[i] = r[i];
+        }
+    }
+}
+
+// Aligned stores for the fast kernel.  The value just before a thread's four
+// is its exclusive prefix `e`, so thread t can store {e, r0, r1, r2} at element
+// done + 4t of the output instead of {r0..r3} at element done + 4t + 1: the
+// same bytes overall, but every 16-byte store is 16-byte aligned.  Element
+// done + TILE (r3 of the last thread) is written by the next tile, or by the
+// caller after the last tile.
+template <typename U>
+__device__ inline void tile_store_shifted_full(gptr<U> out, uint32_t done, U e, const U (&r)[4]) {
+    const uint64_t ot = (uint64_t)(uintptr_t)out + (uint64_t)done * sizeof(U);
+    const uint32_t ot_lo = __builtin_amdgcn_readfirstlane((uint32_t)ot);
+    const uint32_t ot_hi = __builtin_amdgcn_readfirstlane((uint32_t)(ot >> 32));
+    gptr<U> o = (gptr<U>)(((uint64_t)ot_hi << 32) | ot_lo) + threadIdx.x * 4;
+    if (sizeof(U) == 8) {
+        u64x2_a8 a, b2;
+        a.x = (uint64_t)e; a.y = (uint64_t)r[0];
+        b2.x = (uint64_t)r[1]; b2.y = (uint64_t)r[2];
+        *(gptr<u64x2_a8>)(o) = a;
+        *(gptr<u64x2_a8>)(o + 2) = b2;
+    } else {
+        u32x4_a4 a;
+        a.x = (uint32_t)e; a.y = (uint32_t)r[0];
+        a.z = (uint32_t)r[1]; a.w = (uint32_t)r[2];
+        *(gptr<u32x4_a4>)(o) = a;
+    }
+}
+
+// A tile of fewer than TILE deltas: elements done .. done + count.
+template <typename U>
+__device__ inline void tile_store_shifted_partial(gptr<U> out, uint32_t done, uint32_t count, U e, const U (&r)[4]) {
+    const uint32_t j = threadIdx.x * 4;
+    gptr<U> o = out + done + j;
+    if (j <= count) o[0] = e;
+    for (uint32_t k = 1; k < 4; k++)
+        if (j + k <= count) o[k] = r[k - 1];
+}
+
+template <typename U>
+__device__ inline void decode_tile(const uint32_t* ring, uint64_t* wtot, const Slot s, gptr<U> out, uint64_t done, uint32_t count,
+                                   uint32_t within, U& carry) {
+    U r[4];
+    tile_values<U, false>(ring, wtot, s, count, within, carry, r);
+    tile_store<U>(out, done, count, r);
+}
 
 // ---------------------------------------------------------------------------
 // Fast path: block sizes 128/256/512/1024 with at most 32 miniblocks (every
 // writer in practice; the reference writes 128/4).  A tile is then a whole
-// number of blocks, and wave 0 finds the tile's block headers in parallel:
-// lane l guesses that block l starts l * S bytes after the first one, S being
-// the size of the block before, parses the header it finds there and the
-// guess holds for every lane whose predecessors all measured S again.  With
-// steady widths one round finds all blocks of a tile; when every block differs
-// the walk degrades to one block per round, still all in LDS.
+// number of blocks, and wave 0 finds block headers for up to four tiles at a
+// time, in parallel: lane l guesses that block l starts l * S bytes after the
+// first one, S being the size of the block before, parses the header it finds
+// there, and the guess holds for every lane whose predecessors all measured S
+// again.  With steady widths one round finds 32 blocks; when every block
+// differs the walk degrades to one block per round, still all in LDS.
 // Pages of any other geometry are left to the general kernel below.
 // ---------------------------------------------------------------------------
 
 constexpr uint64_t FAST_DONE = 0x46415354444f4e45ull; // marks a result the fast kernel produced
+constexpr uint32_t TBL_TILES = 4;    // tiles one walk can describe
+constexpr uint32_t TBL_SLOTS = TBL_TILES * 32;  // miniblocks one walk can describe
+constexpr uint32_t TBL_BLOCKS = TBL_TILES * 8; // blocks one walk can describe
+constexpr uint32_t HDR_MAX = 10 + 32; // longest block header the fast path reads
+constexpr uint64_t FAST_MAX_BYTES = 0xfff00000ull; // pages the fast path addresses with 32-bit offsets
+
+// Everything below is in ring space (byte offsets from the 16-byte aligned
+// base of the page), 32 bits wide.
+struct FastCtl {
+    uint32_t tile_lo[TBL_TILES + 1]; // start of every tile's bytes; [tiles] = start of what follows
+    uint32_t consumed;
+    uint32_t tiles;      // tiles described by the table
+    uint32_t got;        // deltas described by the table
+    int32_t status;      // status to report once the table is used up
+    int32_t stop;        // nonzero: nothing follows the table
+    int64_t arg;
+};
+
+struct FastShared {
+    uint32_t ring[RING_BYTES / 4 + 4]; // + mirror of the first 16 bytes, so a field never wraps
+    Slot slots[TBL_SLOTS];
+    uint32_t blk_end[TBL_BLOCKS];
+    uint64_t wtot[DT / 64];
+    Ctl ctl;
+    FastCtl fc;
+};
+
+// Go's binary.Uvarint over ring bytes [pos, end), 32-bit positions.
+__device__ inline int ring_uvarint32(const uint8_t* ring8, uint32_t pos, uint32_t end, uint64_t* out) {
+    uint64_t x = 0;
+    unsigned s = 0;
+    for (int i = 0;; i++) {
+        if (pos + i >= end) { *out = 0; return 0; }
+        if (i == 10) return -(i + 1);
+        uint32_t b = ring8[(pos + i) & RING_MASK];
+        if (b < 0x80) {
+            if (i == 9 && b > 1) return -(i + 1);
+            *out = x | ((uint64_t)b << s);
+            return i + 1;
+        }
+        x |= (uint64_t)(b & 0x7f) << s;
+        s += 7;
+    }
+}
+
+// Synchronous top-up of the ring: chunks c_next .. lo/CHUNK + 3.
+__device__ inline void ring_fill32(uint32_t* ring, gptr<const uint8_t> base, uint32_t end, uint32_t lo, uint32_t& c_next) {
+    const uint32_t c_lo = lo / CHUNK;
+    if (c_next < c_lo) c_next = c_lo;
+    const uint32_t c_stop = c_lo + LOOK / CHUNK;
+    while (c_next <= c_stop) {
+        const uint32_t v = c_next * CHUNK + threadIdx.x * 16u;
+        const uint32_t vs = v < end ? v : 0u; // always a readable address; ring_put discards what lies past the end
+        const u32x4 w = *(gptr<const u32x4>)(base + vs);
+        ring_put(ring, v, end, w);
+        c_next++;
+    }
+}
 
 template <typename U>
-__global__ __launch_bounds__(DT) void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
-                                                       const uint32_t* __restrict__ items) {
-    __shared__ Shared sh;
+__global__ __launch_bounds__(DT) __attribute__((amdgpu_waves_per_eu(8, 8), amdgpu_num_sgpr(80)))
+void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                       const uint32_t* __restrict__ items) {
+    __shared__ FastShared sh;
     const uint32_t item = items[blockIdx.x];
     const DevPage& pg = pages[item];
     DevResult* res = &results[item];
@@ -284,13 +440,17 @@ __global__ __launch_bounds__(DT) void delta_fast_kernel(const DevPage* __restric
     if (pg.chain >= 0) src_skip = results[pg.chain].consumed;
     const uint8_t* src = pg.src + src_skip;
     const uint64_t src_len = pg.src_len > src_skip ? pg.src_len - src_skip : 0;
-    const uint64_t mis = reinterpret_cast<uintptr_t>(src) & 15;
-    const uint8_t* base = src - mis;
-    const uint64_t end = mis + src_len;
-    U* out = reinterpret_cast<U*>(pg.dst);
+    const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15);
+    gptr<const uint8_t> base = as_global(src - mis);
+    gptr<U> out = (gptr<U>)(pg.dst);
+    if (src_len > FAST_MAX_BYTES) { // uniform: left to the general kernel, which addresses with 64 bits
+        if (tid == 0) res->aux = 0;
+        return;
+    }
+    const uint32_t end = mis + (uint32_t)src_len;
 
-    uint64_t c_next = 0;
-    ring_fill(sh.ring, base, end, mis, c_next);
+    uint32_t c_next = 0;
+    ring_fill32(sh.ring, base, end, mis, c_next);
     __syncthreads();
 
     if (tid == 0) {
@@ -310,131 +470,214 @@ __global__ __launch_bounds__(DT) void delta_fast_kernel(const DevPage* __restric
         return;
     }
 
-    const uint64_t total = sh.ctl.total;
+    const uint32_t total = (uint32_t)sh.ctl.total;          // <= MaxInt32
     const uint32_t vpm = sh.ctl.vpm;
     const uint32_t nmb = sh.ctl.slot_base;
     const uint32_t block_size = sh.ctl.count;
     const uint32_t vpm_shift = vpm ? 31 - __clz(vpm) : 0;
     const uint32_t blk_shift = block_size ? 31 - __clz(block_size) : 0;
+    const uint32_t nb_tile = block_size ? TILE >> blk_shift : 1;       // blocks per tile
+    const uint32_t slots_tile = vpm ? TILE >> vpm_shift : 1;           // miniblocks per tile
     int stop = sh.ctl.stop;
+    int32_t status = sh.ctl.status;
+    int64_t status_arg = sh.ctl.arg;
+    uint32_t consumed = (uint32_t)sh.ctl.consumed;
     U carry = (U)sh.ctl.first;
-    uint64_t done = 0;
-    const uint64_t n_deltas = total > 0 ? total - 1 : 0;
-    // wave 0 only: start of the next block and the size guess
-    uint64_t pos = sh.ctl.lo;
-    uint32_t guess = 0;
+    uint32_t done = 0;
+    const uint32_t n_deltas = total > 0 ? total - 1 : 0;
+    uint32_t lo = (uint32_t)sh.ctl.lo;   // start of the next tile's bytes
+    uint32_t guess = 0;                  // wave 0: size of the last block walked
+    uint32_t tbl_tiles = 0, tbl_next = 0, tbl_got = 0;
     __syncthreads();
+
+    // chunks loaded during the previous tile, still in registers: pf_n of them, the first at ring offset pf_v
+    uint32_t pf_n = 0, pf_v = 0;
+    u32x4 pf0 = (u32x4)(0u), pf1 = (u32x4)(0u);
 
     while (!stop) {
-        ring_fill(sh.ring, base, end, sh.ctl.lo, c_next);
-        __syncthreads(); // B1
+        // The chunks requested one tile ago go into the ring now: every wave is past the
+        // ring reads of that tile (barrier inside tile_values), and the loads have had a
+        // whole tile to land.  The tile's own stores were issued after them, so waiting
+        // for these loads does not wait for those stores (memory ops retire in order).
+        if (pf_n > 0) {
+            ring_put(sh.ring, pf_v, end, pf0);
+            if (pf_n > 1) ring_put(sh.ring, pf_v + CHUNK, end, pf1);
+            c_next += pf_n;
+            pf_n = 0;
+        }
+        // Top-up: normally a no-op, the prefetch keeps the ring ahead of the tile.
+        ring_fill32(sh.ring, base, end, lo, c_next);
+        lds_barrier(); // B1: ring bytes (prefetched or topped up) visible
 
-        const uint32_t want = (uint32_t)(n_deltas - done < TILE ? n_deltas - done : TILE);
-        if (tid < 64) {
-            const uint32_t nb_want = (want + block_size - 1) >> blk_shift;
-            uint32_t found = 0, got = 0;
-            int32_t status = PQD_OK;
-            int64_t arg = 0;
-            while (found < nb_want) {
-                const bool active = lane < nb_want - found;
-                const uint64_t cand = pos + (uint64_t)lane * guess;
-                // values this block still has to deliver, and the miniblocks that hold them
-                const uint32_t bidx = found + lane;
-                const uint32_t bvals = active ? (want - (bidx << blk_shift) < block_size ? want - (bidx << blk_shift) : block_size) : 0;
-                const uint32_t need_mb = (bvals + vpm - 1) >> vpm_shift;
-                int32_t err = PQD_OK;
-                int64_t err_arg = 0;
-                bool at_end = false;
-                uint32_t size = 0, have_mb = 0;
-                if (active) {
-                    if (cand >= end) {
-                        at_end = true;
-                    } else {
-                        uint64_t z;
-                        int k = ring_uvarint(ring8, cand, end, &z);
-                        if (k == 0) { err = PQD_ERR_UNEXPECTED_EOF; err_arg = PQD_EOF_DELTA_MIN_DELTA; }
-                        else if (k < 0) { err = PQD_ERR_VARINT_OVERFLOW; err_arg = (int64_t)(cand - mis); }
-                        else {
-                            const int64_t md = unzigzag(z);
-                            const uint64_t wpos = cand + k;
-                            const uint32_t nbw = end - wpos < nmb ? (uint32_t)(end - wpos) : nmb;
-                            uint64_t off = wpos + nbw;
-                            have_mb = nbw < need_mb ? nbw : need_mb;
-                            for (uint32_t m = 0; m < have_mb; m++) {
-                                const uint32_t bw = ring8[(wpos + m) & RING_MASK];
-                                if (bw > Elem<U>::max_bw) { err = PQD_ERR_INVALID_BIT_WIDTH; err_arg = bw; have_mb = m; break; }
-                                Slot sl;
-                                sl.min_delta = md; sl.off = off; sl.bw = bw; sl.pad = 0;
-                                sh.slots[(bidx << (blk_shift - vpm_shift)) + m] = sl;
-                                off += ((uint64_t)vpm * bw) >> 3;
+        if (tbl_next == tbl_tiles) {
+            if (tid < 64) {
+                // ---- walk: block headers of up to TBL_TILES tiles, starting at lo ----
+                const uint32_t win_hi = (lo / CHUNK + LOOK / CHUNK + 1) * CHUNK; // resident bytes end here
+                const uint32_t rem = n_deltas - done;
+                const uint32_t blocks_left = (rem + block_size - 1) >> blk_shift;
+                const uint32_t target = blocks_left < TBL_TILES * nb_tile ? blocks_left : TBL_TILES * nb_tile;
+                const uint32_t enough = target < nb_tile ? target : nb_tile; // one tile, or what the page still has
+                uint32_t pos = lo;
+                uint32_t found = 0, last_vals = 0;
+                int32_t wstatus = PQD_OK;
+                int64_t warg = 0;
+                bool ended = false;
+                while (found < enough) {
+                    const uint32_t bidx = found + lane;
+                    const uint32_t cand = pos + lane * guess;
+                    const bool parsed = bidx < target && (lane == 0 || cand + HDR_MAX <= win_hi || win_hi >= end);
+                    // values this block still has to deliver, and the miniblocks that hold them
+                    const uint32_t before = bidx << blk_shift;
+                    const uint32_t bvals = parsed ? (rem - before < block_size ? rem - before : block_size) : 0;
+                    const uint32_t need_mb = (bvals + vpm - 1) >> vpm_shift;
+                    int32_t err = PQD_OK;
+                    int64_t err_arg = 0;
+                    bool at_end = false;
+                    uint32_t size = 0, have_mb = 0;
+                    if (parsed) {
+                        if (cand >= end) {
+                            at_end = true;
+                        } else {
+                            uint64_t z;
+                            int k = ring_uvarint32(ring8, cand, end, &z);
+                            if (k == 0) { err = PQD_ERR_UNEXPECTED_EOF; err_arg = PQD_EOF_DELTA_MIN_DELTA; }
+                            else if (k < 0) { err = PQD_ERR_VARINT_OVERFLOW; err_arg = (int64_t)(cand - mis); }
+                            else {
+                                const int64_t md = unzigzag(z);
+                                const uint32_t wpos = cand + k;
+                                const uint32_t nbw = end - wpos < nmb ? end - wpos : nmb;
+                                uint32_t off = wpos + nbw;
+                                have_mb = nbw < need_mb ? nbw : need_mb;
+                                for (uint32_t m = 0; m < have_mb; m++) {
+                                    const uint32_t bw = ring8[(wpos + m) & RING_MASK];
+                                    if (bw > Elem<U>::max_bw) { err = PQD_ERR_INVALID_BIT_WIDTH; err_arg = bw; have_mb = m; break; }
+                                    Slot sl;
+                                    sl.min_delta = md; sl.off = off; sl.bw = bw;
+                                    sh.slots[bidx * nmb + m] = sl;
+                                    off += (vpm * bw) >> 3;
+                                }
+                                size = off - cand;
+                                sh.blk_end[bidx] = off;
                             }
-                            size = (uint32_t)(off - cand);
                         }
                     }
-                }
-                const bool bad = err != PQD_OK || at_end;
-                const bool ok = active && !bad && size == guess;
-                const unsigned long long okmask = __ballot(ok);
-                const unsigned long long badmask = __ballot(active && bad);
-                uint32_t lead = okmask == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~okmask);
-                uint32_t valid = lead + 1 < nb_want - found ? lead + 1 : nb_want - found;
-                if ((badmask >> (valid - 1)) & 1) {
-                    if (valid == 1) { // the block the stream really continues with is unreadable
+                    const bool bad = parsed && (err != PQD_OK || at_end);
+                    const bool good = parsed && !bad;
+                    const unsigned long long okmask = __ballot(good && size == guess);
+                    const unsigned long long goodmask = __ballot(good);
+                    const uint32_t lead = okmask == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~okmask);
+                    uint32_t valid = lead < 64 ? lead + (uint32_t)((goodmask >> lead) & 1) : 64u;
+                    if (valid > target - found) valid = target - found;
+                    if (valid == 0) { // the block the stream really continues with is unreadable
                         const int32_t e0 = __shfl(err, 0);
                         const int64_t a0 = __shfl(err_arg, 0);
-                        if (e0 != PQD_OK) { status = e0; arg = a0; }
-                        else { status = PQD_ERR_MISSING_VALUES; arg = (int64_t)(n_deltas - done - got); }
+                        if (e0 != PQD_OK) { wstatus = e0; warg = a0; }
+                        else { wstatus = PQD_ERR_MISSING_VALUES; }
+                        ended = true;
                         break;
                     }
-                    valid--; // report it when it is first in line
+                    const uint32_t last = valid - 1;
+                    const uint32_t l_have = __shfl(have_mb, last);
+                    const uint32_t l_need = __shfl(need_mb, last);
+                    const uint32_t l_vals = __shfl(bvals, last);
+                    const uint32_t l_size = __shfl(size, last);
+                    const uint32_t l_cand = __shfl(cand, last);
+                    found += valid;
+                    pos = l_cand + l_size;
+                    guess = l_size;
+                    last_vals = l_have < l_need ? l_have << vpm_shift : l_vals;
+                    if (l_have < l_need) { // the widths ran out: nothing follows this block
+                        wstatus = PQD_ERR_MISSING_VALUES;
+                        ended = true;
+                        break;
+                    }
                 }
-                const uint32_t last = valid - 1;
-                const uint32_t last_have = __shfl(have_mb, last);
-                const uint32_t last_need = __shfl(need_mb, last);
-                const uint32_t last_vals = __shfl(bvals, last);
-                const uint32_t last_size = __shfl(size, last);
-                const uint64_t last_cand = __shfl(cand, last);
-                found += valid;
-                got = ((found - 1) << blk_shift) + (last_have < last_need ? last_have << vpm_shift : last_vals);
-                pos = last_cand + last_size;
-                guess = last_size;
-                if (last_have < last_need) { // the widths ran out: nothing follows this block
-                    status = PQD_ERR_MISSING_VALUES;
-                    arg = (int64_t)(n_deltas - done - got);
-                    break;
+                // keep whole tiles unless the stream or the page ends inside the table
+                const bool page_end = found == blocks_left && !ended;
+                if (!ended && !page_end) found = (found / nb_tile) * nb_tile;
+                const uint32_t got = found ? ((found - 1) << blk_shift) + (found == blocks_left || ended ? last_vals : block_size) : 0;
+                const uint32_t tiles = (got + TILE - 1) / TILE;
+                if (tid == 0) {
+                    FastCtl& f = sh.fc;
+                    f.tiles = tiles;
+                    f.got = got;
+                    f.tile_lo[0] = lo;
+                    for (uint32_t t = 1; t <= tiles; t++) {
+                        uint32_t lastblk = t * nb_tile < found ? t * nb_tile : found;
+                        f.tile_lo[t] = sh.blk_end[lastblk - 1];
+                    }
+                    const uint32_t fin = found ? sh.blk_end[found - 1] : lo;
+                    f.consumed = fin < end ? fin : end;
+                    f.status = wstatus;
+                    f.arg = wstatus == PQD_ERR_MISSING_VALUES ? (int64_t)(rem - got) : warg;
+                    f.stop = (ended || page_end) ? 1 : 0;
                 }
             }
-            if (tid == 0) {
-                Ctl& c = sh.ctl;
-                c.count = got;
-                c.lo = pos;
-                c.consumed = pos < end ? pos : end;
-                if (status != PQD_OK) { c.status = status; c.arg = arg; }
-                if (status != PQD_OK || done + got >= n_deltas) c.stop = 1;
+            lds_barrier(); // B2: table visible
+            tbl_tiles = sh.fc.tiles;
+            tbl_got = sh.fc.got;
+            tbl_next = 0;
+            if (tbl_tiles == 0) { // nothing decodable: the pending status ends the page
+                status = sh.fc.status; status_arg = sh.fc.arg; consumed = sh.fc.consumed;
+                break;
             }
         }
-        __syncthreads(); // B2
 
-        const uint32_t count = sh.ctl.count;
-        stop = sh.ctl.stop;
+        const uint32_t left = tbl_got - tbl_next * TILE;
+        const uint32_t count = left < TILE ? left : TILE;
         const uint32_t j = tid * 4;
-        decode_tile<U>(sh, out, done, count, j >> vpm_shift, j & (vpm - 1), carry);
+        const uint32_t slot = tbl_next * slots_tile + (j >> vpm_shift);
+        U r[4];
+        if (count < TILE) {
+            // The last tile of the page, kept off the loop's back edge: the pipelined path
+            // below relies on every thread issuing the same memory operations per iteration.
+            const U e = tile_values<U, true>(sh.ring, sh.wtot, j < count ? sh.slots[slot] : Slot{0, 0, 0}, count, j & (vpm - 1), carry, r);
+            tile_store_shifted_partial<U>(out, done, count, e, r);
+            done += count;
+            status = sh.fc.status; status_arg = sh.fc.arg; consumed = sh.fc.consumed;
+            break;
+        }
+
+        // ---- prefetch: chunks the NEXT tile wants resident, requested now and written to
+        // the ring at the top of the next iteration.  Both loads are issued on every
+        // iteration (of a dummy address when there is nothing to fetch) and every thread
+        // then issues exactly two stores, so the wait for these loads at the top of the
+        // next iteration is a fixed "all but the two youngest operations".  Addresses are
+        // clamped, so a load is always legal; ring_put discards what lies past the end. ----
+        const uint32_t lo_next = sh.fc.tile_lo[tbl_next + 1];
+        const uint32_t c_want = lo_next / CHUNK + LOOK / CHUNK; // last chunk the next tile wants
+        pf_n = c_next > c_want ? 0u : (c_want + 1 - c_next > 2 ? 2u : c_want + 1 - c_next);
+        pf_v = c_next * CHUNK + tid * 16u;
+        {
+            const uint32_t pv1 = pf_v + CHUNK;
+            pf0 = *(gptr<const u32x4>)(base + (pf_n > 0 && pf_v < end ? pf_v : 0u));
+            pf1 = *(gptr<const u32x4>)(base + (pf_n > 1 && pv1 < end ? pv1 : 0u));
+        }
+
+        const U e = tile_values<U, true>(sh.ring, sh.wtot, sh.slots[slot], TILE, j & (vpm - 1), carry, r);
+        tile_store_shifted_full<U>(out, done, e, r);
         done += count;
+        tbl_next++;
+        lo = lo_next;
+        if (tbl_next == tbl_tiles && sh.fc.stop) {
+            status = sh.fc.status; status_arg = sh.fc.arg; consumed = sh.fc.consumed;
+            stop = 1;
+        }
     }
 
     __syncthreads();
-    const int32_t status = sh.ctl.status;
     if (status == PQD_ERR_MISSING_VALUES || status == PQD_ERR_UNEXPECTED_EOF || status == PQD_ERR_VARINT_OVERFLOW ||
         status == PQD_ERR_INVALID_BIT_WIDTH) {
-        for (uint64_t k = 1 + done + tid; k < total; k += DT) out[k] = 0;
+        for (uint32_t k = 1 + done + tid; k < total; k += DT) out[k] = 0;
     }
     if (tid == 0) {
+        if (done > 0) out[done] = carry; // the element a full last tile leaves to its successor
         res->status = status;
-        res->arg = sh.ctl.arg;
+        res->arg = status_arg;
         res->total = total;
         res->out_values = total;
-        res->out_bytes = total * sizeof(U);
-        res->consumed = src_skip + (sh.ctl.consumed - mis);
+        res->out_bytes = (uint64_t)total * sizeof(U);
+        res->consumed = src_skip + (consumed - mis);
         res->n_runs = 0;
         res->aux = FAST_DONE;
     }
@@ -457,9 +700,9 @@ __global__ __launch_bounds__(DT) void delta_decode_kernel(const DevPage* __restr
     const uint8_t* src = pg.src + src_skip;
     const uint64_t src_len = pg.src_len > src_skip ? pg.src_len - src_skip : 0;
     const uint64_t mis = reinterpret_cast<uintptr_t>(src) & 15;
-    const uint8_t* base = src - mis;       // ring-space 0
+    gptr<const uint8_t> base = as_global(src - mis);       // ring-space 0
     const uint64_t end = mis + src_len;    // ring-space end of page
-    U* out = reinterpret_cast<U*>(pg.dst);
+    gptr<U> out = (gptr<U>)(pg.dst);
     if (res->aux == FAST_DONE) return; // uniform: the fast kernel decoded this page
 
     uint64_t c_next = 0;
@@ -536,7 +779,7 @@ __global__ __launch_bounds__(DT) void delta_decode_kernel(const DevPage* __restr
                             if (nb == 0) continue; // nothing but a min delta was left
                         }
                         uint32_t bw = wk.nbw_in_block <= BW_CACHE ? sh.blk_bw[wk.mb_in_block]
-                                                                  : base[wk.bw_pos + wk.mb_in_block];
+                                                                  : (uint32_t)base[wk.bw_pos + wk.mb_in_block];
                         wk.mb_in_block++;
                         if (bw > Elem<U>::max_bw) { c.status = PQD_ERR_INVALID_BIT_WIDTH; c.arg = bw; break; }
                         uint64_t mbsize = (uint64_t)vpm * bw / 8;
@@ -550,7 +793,7 @@ __global__ __launch_bounds__(DT) void delta_decode_kernel(const DevPage* __restr
                     }
                     uint32_t take = wk.cur_rem < want - got ? wk.cur_rem : want - got;
                     Slot s;
-                    s.min_delta = wk.min_delta; s.off = wk.cur_off; s.bw = wk.cur_bw; s.pad = 0;
+                    s.min_delta = wk.min_delta; s.off = (uint32_t)wk.cur_off; s.bw = wk.cur_bw;
                     sh.slots[nslots++] = s;
                     wk.cur_rem -= take;
                     wk.cur_within += take;
@@ -579,7 +822,7 @@ __global__ __launch_bounds__(DT) void delta_decode_kernel(const DevPage* __restr
             within = (uint32_t)(g - (uint64_t)mb * vpm);
             slot = mb - sh.ctl.slot_base;
         }
-        decode_tile<U>(sh, out, done, count, slot, within, carry);
+        decode_tile<U>(sh.ring, sh.wtot, j < count ? sh.slots[slot] : Slot{0, 0, 0}, out, done, count, within, carry);
         done += count;
     }
 

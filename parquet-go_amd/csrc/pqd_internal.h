@@ -83,6 +83,17 @@ enum Family : int32_t {
     FAM_ERROR = 11      // rejected on the host; status already set
 };
 
+// Pointers read out of a descriptor are generic to the compiler, which then
+// emits FLAT loads and stores: those count on both the vector-memory and the
+// LDS counter, so every LDS wait would also wait for outstanding global stores.
+// Kernels cast descriptor pointers to the global address space before use.
+template <typename T> using gptr = __attribute__((address_space(1))) T*;
+template <typename T> __device__ inline gptr<T> as_global(T* p) { return (gptr<T>)p; }
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint64_t u64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+
 // Failure bookkeeping: the first failing condition in stream order wins; a
 // kernel records one with this helper from a single thread.
 __device__ inline void set_status(DevResult* r, int32_t status, int64_t arg) {

@@ -25,6 +25,20 @@
 namespace pqd {
 namespace {
 
+// A run table entry is moved as one 16-byte vector.
+__device__ inline Run load_run(gptr<const Run> runs, uint64_t i) {
+    const u32x4 w = *(gptr<const u32x4>)(runs + i);
+    Run r;
+    r.out_start = w.x; r.in_off = w.y; r.value = w.z; r.count_kind = w.w;
+    return r;
+}
+
+__device__ inline void store_run(gptr<Run> runs, uint64_t i, const Run& r) {
+    u32x4 w;
+    w.x = r.out_start; w.y = r.in_off; w.z = r.value; w.w = r.count_kind;
+    *(gptr<u32x4>)(runs + i) = w;
+}
+
 // ------------------------------------------------------------------ index --
 
 constexpr int IT = 64;                       // one wavefront
@@ -72,7 +86,7 @@ __global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict
     const uint32_t tid = threadIdx.x;
     const uint8_t* ring8 = reinterpret_cast<const uint8_t*>(ring);
 
-    const uint8_t* src = pg.src;
+    gptr<const uint8_t> src = as_global(pg.src);
     uint64_t src_len = pg.src_len;
     int32_t mode = pg.kind == PQD_KIND_LEVELS ? MODE_LEVELS : (pg.kind == PQD_KIND_BOOLEAN ? MODE_BOOL : MODE_INT32);
     const bool dict_framed = pg.encoding == PQD_ENC_RLE_DICTIONARY || pg.encoding == PQD_ENC_PLAIN_DICTIONARY;
@@ -101,8 +115,8 @@ __global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict
     }
     if (status0 != PQD_OK) src_len = 0;
 
-    const uint64_t mis = reinterpret_cast<uintptr_t>(src) & 15;
-    const uint8_t* base = src - mis;
+    const uint64_t mis = (uintptr_t)src & 15;
+    gptr<const uint8_t> base = src - mis;
     const uint64_t end = mis + src_len;
     if (tid == 0) {
         ctl.pos = mis + start;
@@ -115,7 +129,7 @@ __global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict
     __syncthreads();
 
     uint64_t c_next = 0;
-    Run* runs = pg.runs;
+    gptr<Run> runs = as_global(pg.runs);
     while (!ctl.done) {
         // fill the ring so that [pos, pos + ILOOK) is resident
         const uint64_t pos0 = ctl.pos;
@@ -123,9 +137,9 @@ __global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict
         if (c_next < c_lo) c_next = c_lo;
         while (c_next <= c_lo + ILOOK / ICHUNK) {
             uint64_t v = c_next * ICHUNK + tid * 16u;
-            uint4 w = make_uint4(0, 0, 0, 0);
-            if (v < end) w = *reinterpret_cast<const uint4*>(base + v); // bytes past `end` are never parsed
-            *reinterpret_cast<uint4*>(&ring[(v & IRING_MASK) >> 2]) = w;
+            u32x4 w = (u32x4)(0u);
+            if (v < end) w = *(gptr<const u32x4>)(base + v); // bytes past `end` are never parsed
+            *reinterpret_cast<u32x4*>(&ring[(v & IRING_MASK) >> 2]) = w;
             c_next++;
         }
         __syncthreads();
@@ -174,7 +188,7 @@ __global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict
                 }
                 if (total + nvals > MAX_TOTAL) { status = PQD_ERR_RUN_TOO_LARGE; arg = (int64_t)(total + nvals); break; }
                 r.count_kind = ((uint32_t)nvals << 1) | (bitpacked ? 1u : 0u);
-                runs[n_runs++] = r;
+                store_run(runs, n_runs++, r);
                 total += nvals;
             }
             ctl.pos = pos;
@@ -220,25 +234,27 @@ __device__ inline uint64_t output_count(const DevPage& pg, uint64_t total, bool 
 
 template <int ELEM, bool FUSED>
 __device__ inline void store_value(const DevPage& pg, DevResult* res, uint64_t pos, uint32_t v, uint32_t stride) {
-    uint8_t* p = pg.dst + pos * stride;
+    gptr<uint8_t> p = as_global(pg.dst) + pos * stride;
     if (!FUSED) {
         if (ELEM == 1) *p = (uint8_t)v;
-        else *reinterpret_cast<uint32_t*>(p) = v;
+        else *(gptr<uint32_t>)(p) = v;
         return;
     }
     // Dictionary.Lookup: unsigned bounds check, then gather (dictionary_amd64.s:578-711)
     const bool ok = (uint64_t)v < pg.dict_len;
     if (!ok) atomicMin(reinterpret_cast<unsigned long long*>(&res->aux), (unsigned long long)pos);
-    const uint8_t* d = pg.dict + (uint64_t)(ok ? v : 0) * ELEM;
+    gptr<const uint8_t> d = as_global(pg.dict) + (uint64_t)(ok ? v : 0) * ELEM;
     if (ELEM == 4) {
-        uint32_t x = ok ? *reinterpret_cast<const uint32_t*>(d) : 0u;
-        *reinterpret_cast<uint32_t*>(p) = x;
+        uint32_t x = ok ? *(gptr<const uint32_t>)(d) : 0u;
+        *(gptr<uint32_t>)(p) = x;
     } else if (ELEM == 8) {
-        uint64_t x = ok ? *reinterpret_cast<const uint64_t*>(d) : 0ull;
-        __builtin_memcpy(p, &x, 8);
+        uint64_t x = ok ? *(gptr<const uint64_t>)(d) : 0ull;
+        u32x2_a4 w;
+        w.x = (uint32_t)x; w.y = (uint32_t)(x >> 32);
+        *(gptr<u32x2_a4>)(p) = w; // rows of a strided destination are only 4-byte aligned
     } else {
-        const uint32_t* d32 = reinterpret_cast<const uint32_t*>(d);
-        uint32_t* p32 = reinterpret_cast<uint32_t*>(p);
+        gptr<const uint32_t> d32 = (gptr<const uint32_t>)(d);
+        gptr<uint32_t> p32 = (gptr<uint32_t>)(p);
         for (int k = 0; k < ELEM / 4; k++) p32[k] = ok ? d32[k] : 0u;
     }
 }
@@ -248,11 +264,10 @@ template <int ELEM, bool FUSED>
 __device__ inline void expand_tile(EShared& sh, const DevPage& pg, DevResult* res, uint64_t t0, uint32_t n,
                                    uint64_t total, uint64_t n_runs, uint32_t bw) {
     const uint32_t tid = threadIdx.x;
-    const Run* __restrict__ runs = pg.runs;
+    gptr<const Run> runs = as_global((const Run*)pg.runs);
     const uint32_t stride = pg.dst_stride > 0 ? (uint32_t)pg.dst_stride : (uint32_t)ELEM;
     const bool dense = stride == (uint32_t)ELEM;
-    const uint64_t src_skip = 0;
-    const uint8_t* src = pg.src + src_skip;
+    gptr<const uint8_t> src = as_global(pg.src);
 
     // values past the end of the stream: zero-extended indices (FUSED only)
     uint32_t n_stream = n;
@@ -270,7 +285,7 @@ __device__ inline void expand_tile(EShared& sh, const DevPage& pg, DevResult* re
         r0 = lo;
     }
     Run first = {0, 0, 0, 0};
-    if (n_stream > 0) first = runs[r0];
+    if (n_stream > 0) first = load_run(runs, r0);
     const uint64_t first_end = (uint64_t)first.out_start + (first.count_kind >> 1);
     const bool single = n_stream > 0 && first_end >= t0 + n_stream;
 
@@ -285,13 +300,12 @@ __device__ inline void expand_tile(EShared& sh, const DevPage& pg, DevResult* re
         const uint64_t bit0 = k0 * bw;
         const uint64_t byte0 = (uint64_t)first.in_off + (bit0 >> 3);
         const uint64_t byte1 = (uint64_t)first.in_off + ((bit0 + (uint64_t)n_stream * bw + 7) >> 3);
-        const uintptr_t a0 = reinterpret_cast<uintptr_t>(src + byte0);
-        const uint64_t mis = a0 & 15;
-        const uint8_t* abase = reinterpret_cast<const uint8_t*>(a0 - mis);
+        const uint64_t mis = (uintptr_t)(src + byte0) & 15;
+        gptr<const uint8_t> abase = src + byte0 - mis;
         const uint64_t span = mis + (byte1 - byte0);        // bytes to stage, from the aligned base
         for (uint32_t c = tid * 16; c < span; c += ET * 16) {
-            uint4 w = *reinterpret_cast<const uint4*>(abase + c);
-            *reinterpret_cast<uint4*>(&sh.stage[c >> 2]) = w;
+            u32x4 w = *(gptr<const u32x4>)(abase + c);
+            *reinterpret_cast<u32x4*>(&sh.stage[c >> 2]) = w;
         }
         __syncthreads();
         const uint32_t bitbase = (uint32_t)(mis * 8 + (bit0 & 7));
@@ -308,15 +322,17 @@ __device__ inline void expand_tile(EShared& sh, const DevPage& pg, DevResult* re
                 v[g] = (uint32_t)(w01 >> s) & mask;
             }
             if (!FUSED && dense && j + G <= n_stream) {
-                uint8_t* p = pg.dst + (t0 + j) * ELEM;
+                gptr<uint8_t> p = as_global(pg.dst) + (t0 + j) * ELEM;
                 if (ELEM == 1) {
-                    uint32_t lo = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
-                    uint32_t hi = v[4 % G] | (v[5 % G] << 8) | (v[6 % G] << 16) | (v[7 % G] << 24);
-                    uint2 w = make_uint2(lo, hi);
-                    __builtin_memcpy(p, &w, 8);
+                    u32x2_a4 w;
+                    w.x = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+                    w.y = v[4 % G] | (v[5 % G] << 8) | (v[6 % G] << 16) | (v[7 % G] << 24);
+                    if (((uintptr_t)p & 3) == 0) *(gptr<u32x2_a4>)(p) = w;
+                    else for (int g = 0; g < 8; g++) p[g] = (uint8_t)v[g % G];
                 } else {
-                    uint4 w = make_uint4(v[0], v[1 % G], v[2 % G], v[3 % G]);
-                    __builtin_memcpy(p, &w, 16);
+                    u32x4_a4 w;
+                    w.x = v[0]; w.y = v[1 % G]; w.z = v[2 % G]; w.w = v[3 % G];
+                    *(gptr<u32x4_a4>)(p) = w;
                 }
             } else if (FUSED && dense && ELEM == 8 && j + G <= n_stream) {
                 // gather two 8-byte values, store 16 contiguous bytes
@@ -326,9 +342,11 @@ __device__ inline void expand_tile(EShared& sh, const DevPage& pg, DevResult* re
                     const uint32_t idx = v[g % G];
                     const bool ok = (uint64_t)idx < pg.dict_len;
                     if (!ok) atomicMin(reinterpret_cast<unsigned long long*>(&res->aux), (unsigned long long)(t0 + j + g));
-                    x[g] = ok ? reinterpret_cast<const uint64_t*>(pg.dict)[idx] : 0ull;
+                    x[g] = ok ? ((gptr<const uint64_t>)(pg.dict))[idx] : 0ull;
                 }
-                __builtin_memcpy(pg.dst + (t0 + j) * 8, x, 16);
+                u64x2_a8 w;
+                w.x = x[0]; w.y = x[1];
+                *(gptr<u64x2_a8>)(as_global(pg.dst) + (t0 + j) * 8) = w;
             } else if (FUSED && dense && ELEM == 4 && j + G <= n_stream) {
                 uint32_t x[4];
 #pragma unroll
@@ -336,9 +354,11 @@ __device__ inline void expand_tile(EShared& sh, const DevPage& pg, DevResult* re
                     const uint32_t idx = v[g % G];
                     const bool ok = (uint64_t)idx < pg.dict_len;
                     if (!ok) atomicMin(reinterpret_cast<unsigned long long*>(&res->aux), (unsigned long long)(t0 + j + g));
-                    x[g] = ok ? reinterpret_cast<const uint32_t*>(pg.dict)[idx] : 0u;
+                    x[g] = ok ? ((gptr<const uint32_t>)(pg.dict))[idx] : 0u;
                 }
-                __builtin_memcpy(pg.dst + (t0 + j) * 4, x, 16);
+                u32x4_a4 w;
+                w.x = x[0]; w.y = x[1]; w.z = x[2]; w.w = x[3];
+                *(gptr<u32x4_a4>)(as_global(pg.dst) + (t0 + j) * 4) = w;
             } else {
 #pragma unroll
                 for (int g = 0; g < G; g++)
@@ -361,12 +381,12 @@ __device__ inline void expand_tile(EShared& sh, const DevPage& pg, DevResult* re
                 uint32_t mid = (lo + hi) >> 1;
                 if ((uint64_t)sh.run_start[mid] <= pos) lo = mid; else hi = mid;
             }
-            const Run rr = runs[r0 + lo];
+            const Run rr = load_run(runs, r0 + lo);
             uint32_t v;
             if (rr.count_kind & 1) {
                 // bytes touched all belong to this run, which the index kernel bounds-checked
                 uint64_t bit = (pos - rr.out_start) * bw;
-                const uint8_t* q = src + rr.in_off + (bit >> 3);
+                gptr<const uint8_t> q = src + rr.in_off + (bit >> 3);
                 uint32_t s = (uint32_t)(bit & 7);
                 uint32_t nb = (s + bw + 7) >> 3;
                 uint64_t acc = 0;
