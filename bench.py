@@ -322,7 +322,7 @@ def main():
                    "parallelism": f"row groups sharded over {world} GPU(s), no data-path collective"},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _traffic("delta"),
-                     "kernel": "delta_decode_kernel<uint64_t>", "kernel_ms": round(avg_kernel_s * 1e3, 4),
+                     "kernel": "delta_fast_kernel<uint64_t>", "kernel_ms": round(avg_kernel_s * 1e3, 4),
                      "algorithmic_bytes": wl.algorithmic_bytes},
     }
 
