@@ -620,6 +620,7 @@ pqo_result pqo_plain_decode_byte_array(uint8_t* dst, uint64_t cap, uint32_t* off
     offsets[nv] = (uint32_t)out;
     r.n_values = nv;
     r.n_bytes = out;
+    r.consumed = n;
     return r;
 }
 

@@ -327,7 +327,7 @@ def plain_encode_byte_array(values) -> bytes:
 
 
 def bss_encode(data, size: int) -> bytes:
-    d = np.ascontiguousarray(data).view(np.uint8).reshape(-1)
+    d = _src(data) if isinstance(data, (bytes, bytearray, memoryview)) else np.ascontiguousarray(data).view(np.uint8).reshape(-1)
     dst = np.zeros(max(d.size, 1), dtype=np.uint8)
     lib().pqo_bss_encode(_p(dst), _p(d), d.size, size)
     return dst[: d.size].tobytes()

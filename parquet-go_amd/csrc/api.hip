@@ -45,8 +45,7 @@ struct pqd_batch {
     uint64_t* d_rle_tile_prefix = nullptr;
     uint64_t rle_tiles = 0;
     // generic tile grids for the element-parallel families
-    uint64_t* d_tile_prefix[16] = {nullptr};
-    uint64_t tiles[16] = {0};
+    uint64_t max_src[16] = {0}; // longest src of each family, sizes the tile grids
     std::vector<DevResult> h_results;
 };
 
@@ -199,7 +198,7 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
     b->map.resize(n_pages);
 
     // ---- classify ----
-    size_t runs_entries = 0;
+    size_t runs_entries = 0, lengths_entries = 0;
     for (uint64_t i = 0; i < n_pages; i++) {
         const pqd_page& p = pages[i];
         PageMap m = {-1, PQD_OK, 0};
@@ -220,8 +219,57 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
             runs_entries += d.runs_cap;
             m.primary = (int32_t)b->items.size();
             b->items.push_back(d);
-        } else {
-            m.host_status = PQD_ERR_NOT_SUPPORTED; // family not wired up yet
+        } else if (family == FAM_DLBA) {
+            // the lengths are decoded straight into the caller's offsets buffer and scanned there
+            if (p.offsets == nullptr && p.offsets_cap > 0) {
+                m.host_status = PQD_ERR_INVALID_ARGUMENT;
+            } else {
+                DevPage l = make_item(p, FAM_DELTA32);
+                l.kind = PQD_KIND_INT32;
+                l.elem_width = 4;
+                l.dst = reinterpret_cast<uint8_t*>(p.offsets);
+                l.dst_cap = p.offsets_cap * 4;
+                const int32_t l_idx = (int32_t)b->items.size();
+                b->items.push_back(l);
+                DevPage d = make_item(p, family);
+                d.chain = l_idx;
+                m.primary = (int32_t)b->items.size();
+                b->items.push_back(d);
+            }
+        } else if (family == FAM_DBA) {
+            // prefix and suffix lengths go to scratch; as many entries as the caller could take values
+            const bool ba = p.kind == PQD_KIND_BYTE_ARRAY;
+            if (ba && p.offsets == nullptr && p.offsets_cap > 0) {
+                m.host_status = PQD_ERR_INVALID_ARGUMENT;
+            } else {
+                const uint64_t size = p.bit_width > 0 ? (uint64_t)p.bit_width : 1;
+                const uint64_t cap = ba ? p.offsets_cap : p.dst_cap / size + 1;
+                DevPage pre = make_item(p, FAM_DELTA32);
+                pre.kind = PQD_KIND_INT32;
+                pre.elem_width = 4;
+                pre.lengths_cap = cap;
+                pre.dst_cap = cap * 4;
+                const int32_t p_idx = (int32_t)b->items.size();
+                b->items.push_back(pre);
+                DevPage suf = pre;
+                suf.family = FAM_DELTA32_CHAINED;
+                suf.chain = p_idx;
+                const int32_t s_idx = (int32_t)b->items.size();
+                b->items.push_back(suf);
+                DevPage d = make_item(p, family);
+                d.chain = s_idx;
+                d.lengths_cap = cap;
+                lengths_entries += 2 * cap + 8;
+                m.primary = (int32_t)b->items.size();
+                b->items.push_back(d);
+            }
+        } else { // FAM_BITPACKED, FAM_BSS, FAM_PLAIN_FIXED, FAM_PLAIN_BYTE_ARRAY: one item, no scratch
+            if (family == FAM_PLAIN_BYTE_ARRAY && p.offsets == nullptr && p.offsets_cap > 0) {
+                m.host_status = PQD_ERR_INVALID_ARGUMENT;
+            } else {
+                m.primary = (int32_t)b->items.size();
+                b->items.push_back(make_item(p, family));
+            }
         }
         b->map[i] = m;
     }
@@ -231,6 +279,7 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
     for (uint32_t k = 0; k < b->items.size(); k++) {
         DevPage& d = b->items[k];
         b->fam[d.family].items.push_back(k);
+        b->max_src[d.family] = std::max<uint64_t>(b->max_src[d.family], d.src_len);
         if (d.family == FAM_RLE) {
             const uint64_t stride = d.dst_stride > 0 ? (uint64_t)d.dst_stride : (uint64_t)d.elem_width;
             uint64_t bound = stride ? d.dst_cap / stride + 1 : 0;
@@ -254,6 +303,7 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
     for (int f = 0; f < 16; f++) o_fam[f] = carve(b->fam[f].items.size() * sizeof(uint32_t));
     const size_t o_rle_prefix = carve(rle_prefix.size() * sizeof(uint64_t));
     const size_t o_runs = carve(runs_entries * sizeof(Run));
+    const size_t o_lengths = carve(lengths_entries * sizeof(int32_t));
     b->arena_bytes = std::max<size_t>(off, 256);
     if (hipMalloc(&b->arena, b->arena_bytes) != hipSuccess) { delete b; return PQD_ERR_DEVICE; }
     uint8_t* a = static_cast<uint8_t*>(b->arena);
@@ -261,8 +311,19 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
     b->d_results = reinterpret_cast<DevResult*>(a + o_results);
     b->d_rle_tile_prefix = reinterpret_cast<uint64_t*>(a + o_rle_prefix);
     Run* runs = reinterpret_cast<Run*>(a + o_runs);
+    int32_t* lengths = reinterpret_cast<int32_t*>(a + o_lengths);
     for (DevPage& d : b->items) {
         if (d.family == FAM_RLE) { d.runs = runs; runs += d.runs_cap; }
+        if (d.family == FAM_DBA) {
+            // [prefix | suffix], each lengths_cap entries (+4 of slack so that vector stores of the decoder stay inside)
+            DevPage& suf = b->items[d.chain];
+            DevPage& pre = b->items[suf.chain];
+            d.lengths = lengths;
+            d.lengths2 = lengths + d.lengths_cap + 4;
+            pre.dst = reinterpret_cast<uint8_t*>(d.lengths);
+            suf.dst = reinterpret_cast<uint8_t*>(d.lengths2);
+            lengths += 2 * d.lengths_cap + 8;
+        }
     }
 
     // ---- upload ----
@@ -287,10 +348,18 @@ int pqd_batch_launch(pqd_batch* b, void* hip_stream) {
     if (b == nullptr) return PQD_ERR_INVALID_ARGUMENT;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA32].dev, (uint32_t)b->fam[FAM_DELTA32].items.size(), false, s);
+    launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA32_CHAINED].dev, (uint32_t)b->fam[FAM_DELTA32_CHAINED].items.size(), false, s);
     launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA64].dev, (uint32_t)b->fam[FAM_DELTA64].items.size(), true, s);
     launch_rle_index(b->d_items, b->d_results, b->fam[FAM_RLE].dev, (uint32_t)b->fam[FAM_RLE].items.size(), s);
     launch_rle_expand(b->d_items, b->d_results, b->fam[FAM_RLE].dev, (uint32_t)b->fam[FAM_RLE].items.size(),
                       b->d_rle_tile_prefix, b->rle_tiles, s);
+    auto fam_n = [&](int f) { return (uint32_t)b->fam[f].items.size(); };
+    launch_bitpacked(b->d_items, b->d_results, b->fam[FAM_BITPACKED].dev, fam_n(FAM_BITPACKED), b->max_src[FAM_BITPACKED] * 8, s);
+    launch_bss(b->d_items, b->d_results, b->fam[FAM_BSS].dev, fam_n(FAM_BSS), b->max_src[FAM_BSS], s);
+    launch_plain_fixed(b->d_items, b->d_results, b->fam[FAM_PLAIN_FIXED].dev, fam_n(FAM_PLAIN_FIXED), b->max_src[FAM_PLAIN_FIXED], s);
+    launch_plain_byte_array(b->d_items, b->d_results, b->fam[FAM_PLAIN_BYTE_ARRAY].dev, fam_n(FAM_PLAIN_BYTE_ARRAY), s);
+    launch_dlba(b->d_items, b->d_results, b->fam[FAM_DLBA].dev, fam_n(FAM_DLBA), b->max_src[FAM_DLBA], s);
+    launch_dba(b->d_items, b->d_results, b->fam[FAM_DBA].dev, fam_n(FAM_DBA), s);
     return hipGetLastError() == hipSuccess ? PQD_OK : PQD_ERR_DEVICE;
 }
 

@@ -1,0 +1,648 @@
+// misc.hip -- the element-parallel and byte-array decoders for gfx950:
+//
+//   BIT_PACKED levels          bitpacked.Encoding.DecodeLevels
+//                              (encoding/bitpacked/bitpacked.go:26-29,75-119)
+//   BYTE_STREAM_SPLIT          bytestreamsplit.Encoding.Decode{Int32,Int64,Float,
+//                              Double,FixedLenByteArray}
+//                              (encoding/bytestreamsplit/bytestreamsplit.go:35-105,
+//                              bytestreamsplit_purego.go:47-83,
+//                              bytestreamsplit_fixedlen.go:13-21)
+//   PLAIN fixed width          plain.Encoding.Decode{Boolean,Int32,...}
+//                              (encoding/plain/plain.go:65-74,96-104, plain_le.go:26-52)
+//   PLAIN byte arrays          plain.Encoding.DecodeByteArray (plain.go:76-94)
+//   DELTA_LENGTH_BYTE_ARRAY    delta.LengthByteArrayEncoding.DecodeByteArray
+//                              (encoding/delta/length_byte_array.go:37-63,
+//                              length_byte_array_purego.go:11-24)
+//   DELTA_BYTE_ARRAY           delta.ByteArrayEncoding.DecodeByteArray /
+//                              DecodeFixedLenByteArray (encoding/delta/byte_array.go:124-174,
+//                              byte_array_purego.go:5-63)
+//
+// The length streams of the two DELTA byte-array encodings are ordinary
+// DELTA_BINARY_PACKED int32 items of the same batch (delta.hip); the kernels
+// here start from their results.
+#include "pqd_internal.h"
+
+namespace pqd {
+namespace {
+
+constexpr int MT = 256;                 // threads per workgroup of the tiled kernels
+constexpr uint32_t MAX_FLBA = 32767;    // encoding.MaxFixedLenByteArraySize (encoding/encoding.go:12-14)
+
+typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+typedef uint32_t u32_a1 __attribute__((aligned(1)));
+
+__device__ inline void finish(DevResult* r, int32_t status, int64_t arg, uint64_t n_values, uint64_t n_bytes,
+                              uint64_t consumed) {
+    r->status = status;
+    r->arg = arg;
+    r->out_values = n_values;
+    r->out_bytes = n_bytes;
+    r->consumed = consumed;
+    r->total = n_values;
+}
+
+// Go shifts of a byte by an unsigned amount: amounts of 8 and more give 0.
+__device__ inline uint32_t shl8(uint32_t v, uint64_t s) { return s >= 8 ? 0u : (v << s) & 0xffu; }
+__device__ inline uint32_t shr8(uint32_t v, uint64_t s) { return s >= 8 ? 0u : (v & 0xffu) >> s; }
+
+// ------------------------------------------------------------- BIT_PACKED --
+
+// One value of the MSB-first stream (bitpacked.go:86-113).
+__device__ inline uint32_t bitpacked_value(gptr<const uint8_t> src, uint64_t n, uint64_t k, uint32_t bw) {
+    const uint64_t bit = k * bw;
+    const uint64_t i = bit >> 3, j = bit & 7, available = 8 - j;
+    const uint32_t mask = (shl8(1, bw) - 1) & 0xffu;
+    if (bw <= available) return shr8(src[i], available - bw) & mask;
+    const uint64_t remaining = bw - available;
+    const uint32_t top = src[i] & ((shl8(1, available) - 1) & 0xffu);
+    uint32_t bottom = 0;
+    if (i + 1 < n) bottom = remaining > 8 ? 0u : shr8(src[i + 1], 8 - remaining);
+    return (shl8(top, remaining) | bottom) & 0xffu;
+}
+
+// grid.x = pages of the family, grid.y = tile slots; a tile is MT * 16 values.
+__global__ __launch_bounds__(MT) void bitpacked_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                       const uint32_t* __restrict__ items) {
+    const uint32_t item = items[blockIdx.x];
+    const DevPage& pg = pages[item];
+    DevResult* res = &results[item];
+    gptr<const uint8_t> src = as_global(pg.src);
+    gptr<uint8_t> dst = as_global(pg.dst);
+    const uint64_t n = pg.src_len;
+    const uint32_t bw = (uint32_t)pg.bit_width;
+    const bool lead = blockIdx.y == 0 && threadIdx.x == 0;
+    if (pg.bit_width < 0) { // a negative width is a caller bug; Go would index out of range
+        if (lead) finish(res, PQD_ERR_INVALID_BIT_WIDTH, pg.bit_width, 0, 0, 0);
+        return;
+    }
+    if (bw == 0 || n == 0) { // bitpacked.go:76-78: one zero level
+        if (lead) {
+            if (pg.dst_cap < 1) finish(res, PQD_ERR_DST_TOO_SMALL, 1, 0, 0, 0);
+            else { dst[0] = 0; finish(res, PQD_OK, 0, 1, 1, n); }
+        }
+        return;
+    }
+    const uint64_t bits = 8 * n;
+    const uint64_t count = bits / bw + (bits % bw ? 1 : 0);
+    if (count > pg.dst_cap) {
+        if (lead) finish(res, PQD_ERR_DST_TOO_SMALL, (int64_t)count, 0, 0, 0);
+        return;
+    }
+    const uint64_t tile = (uint64_t)MT * 16;
+    for (uint64_t t = blockIdx.y; t * tile < count; t += gridDim.y) {
+        for (uint32_t q = 0; q < 4; q++) {
+            const uint64_t k = t * tile + (uint64_t)q * MT * 4 + threadIdx.x * 4;
+            if (k + 4 <= count && ((uintptr_t)(pg.dst + k) & 3) == 0) {
+                uint32_t w = 0;
+                for (uint32_t e = 0; e < 4; e++) w |= bitpacked_value(src, n, k + e, bw) << (8 * e);
+                *(gptr<uint32_t>)(dst + k) = w;
+            } else {
+                for (uint32_t e = 0; e < 4 && k + e < count; e++) dst[k + e] = (uint8_t)bitpacked_value(src, n, k + e, bw);
+            }
+        }
+    }
+    if (lead) finish(res, PQD_OK, 0, count, count, n);
+}
+
+// ------------------------------------------------------ BYTE_STREAM_SPLIT --
+
+__device__ inline int32_t fixed_width(const DevPage& pg) {
+    switch (pg.kind) {
+        case PQD_KIND_BOOLEAN: return 1;
+        case PQD_KIND_INT32: case PQD_KIND_FLOAT: return 4;
+        case PQD_KIND_INT64: case PQD_KIND_DOUBLE: return 8;
+        case PQD_KIND_INT96: return 12;
+        default: return pg.bit_width; // FIXED_LEN_BYTE_ARRAY: the type length
+    }
+}
+
+// Checks shared by BYTE_STREAM_SPLIT and PLAIN fixed-width pages
+// (bytestreamsplit.go:35-105, plain.go:65-74,96-104).  Returns the value count.
+__device__ inline bool fixed_checks(const DevPage& pg, DevResult* res, bool lead, int32_t width, uint64_t* count) {
+    const uint64_t n = pg.src_len;
+    if (pg.kind == PQD_KIND_FIXED_LEN_BYTE_ARRAY && (width <= 0 || (uint32_t)width > MAX_FLBA)) {
+        if (lead) finish(res, PQD_ERR_INVALID_ARGUMENT, width, 0, 0, 0);
+        return false;
+    }
+    if (n % (uint64_t)width) {
+        if (lead) finish(res, PQD_ERR_INVALID_ARGUMENT, (int64_t)n, 0, 0, 0);
+        return false;
+    }
+    if (n > pg.dst_cap) {
+        if (lead) finish(res, PQD_ERR_DST_TOO_SMALL, (int64_t)n, 0, 0, 0);
+        return false;
+    }
+    *count = n / (uint64_t)width;
+    return true;
+}
+
+// dst[k * W + s] = src[s * count + k].  A thread takes four consecutive
+// values: one (unaligned) dword from each of the W streams, transposed in
+// registers, stored as 4 * W contiguous bytes.
+template <int W>
+__device__ inline void bss_tile(gptr<const uint8_t> src, gptr<uint8_t> dst, uint64_t count, uint64_t k) {
+    if (k + 4 <= count) {
+        uint32_t in[W];
+#pragma unroll
+        for (int s = 0; s < W; s++) in[s] = *(gptr<const u32_a1>)(src + (uint64_t)s * count + k);
+        uint32_t out[W]; // value e occupies bytes [e * W, e * W + W)
+#pragma unroll
+        for (int d = 0; d < W; d++) {
+            // output dword d holds bytes 4d .. 4d+3 of the 4*W block: byte b = value (b / W), stream (b % W)
+            uint32_t w = 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const int b = 4 * d + c, e = b / W, s = b % W;
+                w |= ((in[s] >> (8 * e)) & 0xffu) << (8 * c);
+            }
+            out[d] = w;
+        }
+        gptr<uint8_t> o = dst + k * W;
+        if (((uintptr_t)o & 3) == 0) {
+#pragma unroll
+            for (int d = 0; d < W; d++) *(gptr<uint32_t>)(o + 4 * d) = out[d];
+        } else {
+#pragma unroll
+            for (int d = 0; d < W; d++) *(gptr<u32_a1>)(o + 4 * d) = out[d];
+        }
+    } else {
+        for (uint64_t e = k; e < count; e++)
+            for (int s = 0; s < W; s++) dst[e * W + s] = src[(uint64_t)s * count + e];
+    }
+}
+
+__global__ __launch_bounds__(MT) void bss_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                 const uint32_t* __restrict__ items) {
+    const uint32_t item = items[blockIdx.x];
+    const DevPage& pg = pages[item];
+    DevResult* res = &results[item];
+    const bool lead = blockIdx.y == 0 && threadIdx.x == 0;
+    const int32_t width = fixed_width(pg);
+    uint64_t count;
+    if (!fixed_checks(pg, res, lead, width, &count)) return;
+    gptr<const uint8_t> src = as_global(pg.src);
+    gptr<uint8_t> dst = as_global(pg.dst);
+    const uint64_t tile = (uint64_t)MT * 4;
+    for (uint64_t t = blockIdx.y; t * tile < count; t += gridDim.y) {
+        const uint64_t k = t * tile + threadIdx.x * 4;
+        if (k >= count) continue;
+        if (width == 4) bss_tile<4>(src, dst, count, k);
+        else if (width == 8) bss_tile<8>(src, dst, count, k);
+        else {
+            for (uint64_t e = k; e < k + 4 && e < count; e++)
+                for (int32_t s = 0; s < width; s++) dst[e * (uint64_t)width + s] = src[(uint64_t)s * count + e];
+        }
+    }
+    if (lead) finish(res, PQD_OK, 0, count, pg.src_len, pg.src_len);
+}
+
+// ------------------------------------------------------------------- copy --
+
+// Copies n bytes; the caller gives every workgroup of the page the same
+// arguments.  16 bytes per thread and step, destination aligned.
+__device__ inline void copy_span(gptr<uint8_t> dst, gptr<const uint8_t> src, uint64_t n) {
+    if (n == 0 || (uintptr_t)dst == (uintptr_t)src) return;
+    const uint64_t head = ((16 - ((uintptr_t)dst & 15)) & 15) < n ? ((16 - ((uintptr_t)dst & 15)) & 15) : n;
+    const uint64_t body = (n - head) / 16;
+    const uint64_t tail0 = head + body * 16;
+    if (blockIdx.y == 0) {
+        for (uint64_t i = threadIdx.x; i < head; i += MT) dst[i] = src[i];
+        for (uint64_t i = tail0 + threadIdx.x; i < n; i += MT) dst[i] = src[i];
+    }
+    for (uint64_t c = (uint64_t)blockIdx.y * MT + threadIdx.x; c < body; c += (uint64_t)gridDim.y * MT) {
+        const u32x4_a1 w = *(gptr<const u32x4_a1>)(src + head + c * 16);
+        *(gptr<u32x4>)(dst + head + c * 16) = w;
+    }
+}
+
+__global__ __launch_bounds__(MT) void plain_fixed_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                         const uint32_t* __restrict__ items) {
+    const uint32_t item = items[blockIdx.x];
+    const DevPage& pg = pages[item];
+    DevResult* res = &results[item];
+    const bool lead = blockIdx.y == 0 && threadIdx.x == 0;
+    const int32_t width = fixed_width(pg);
+    uint64_t count;
+    if (!fixed_checks(pg, res, lead, width, &count)) return;
+    copy_span(as_global(pg.dst), as_global(pg.src), pg.src_len);
+    if (lead) finish(res, PQD_OK, 0, count, pg.src_len, pg.src_len);
+}
+
+// ------------------------------------------------------ PLAIN byte arrays --
+
+constexpr int WT = 64;                   // the walkers below run one wavefront per page
+constexpr uint32_t PSTAGE = 8192;        // bytes of the page staged in LDS at a time
+constexpr uint32_t PBATCH = 64;          // values handled per round
+
+// Fills LDS bytes [0, n) from global memory: 16 bytes per lane and step, then the tail.
+__device__ inline void stage_fill(uint8_t* stage, gptr<const uint8_t> src, uint64_t n, uint32_t lane) {
+    const uint64_t body = n / 16;
+    for (uint64_t c = lane; c < body; c += WT) {
+        const u32x4_a1 w = *(gptr<const u32x4_a1>)(src + c * 16);
+        *reinterpret_cast<u32x4*>(stage + c * 16) = w;
+    }
+    for (uint64_t b = body * 16 + lane; b < n; b += WT) stage[b] = src[b];
+}
+
+__device__ inline uint32_t le32(const uint8_t* p) {
+    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
+}
+
+// plain.go:76-94: a walk over `u32 length | bytes` records.  Lane 0 walks the
+// lengths of up to 64 records out of an LDS copy of the page, then the wave
+// copies their bytes.
+__global__ __launch_bounds__(WT) void plain_byte_array_kernel(const DevPage* __restrict__ pages,
+                                                              DevResult* __restrict__ results,
+                                                              const uint32_t* __restrict__ items) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[PSTAGE];
+    __shared__ uint32_t v_pos[PBATCH], v_len[PBATCH];
+    __shared__ uint32_t ctl[6];
+    const uint32_t item = items[blockIdx.x];
+    const DevPage& pg = pages[item];
+    DevResult* res = &results[item];
+    gptr<const uint8_t> src = as_global(pg.src);
+    gptr<uint8_t> dst = as_global(pg.dst);
+    gptr<uint32_t> offsets = as_global(pg.offsets);
+    const uint64_t n = pg.src_len;
+    const uint32_t lane = threadIdx.x;
+    uint64_t i = 0, out = 0, nv = 0;
+    int32_t status = PQD_OK;
+    int64_t arg = 0;
+    while (i < n && status == PQD_OK) {
+        // stage [i, i + PSTAGE)
+        const uint64_t avail = n - i < PSTAGE ? n - i : PSTAGE;
+        stage_fill(stage, src + i, avail, lane);
+        __syncthreads();
+        if (lane == 0) {
+            uint64_t p = 0, o = out, cnt = 0;
+            int32_t st = PQD_OK;
+            int64_t a = 0;
+            uint32_t big = 0; // a record that does not fit the stage: handled on its own
+            while (cnt < PBATCH && i + p < n) {
+                if (n - (i + p) < 4) { st = PQD_ERR_UNEXPECTED_EOF; a = PQD_EOF_PLAIN_BYTE_ARRAY; break; }
+                if (p + 4 > avail) break; // header not staged: next round starts at it
+                const uint64_t len = le32(stage + p);
+                if (len > n - 4 || len > n - (i + p + 4)) { st = PQD_ERR_UNEXPECTED_EOF; a = PQD_EOF_PLAIN_BYTE_ARRAY; break; }
+                if (nv + cnt + 2 > pg.offsets_cap) { st = PQD_ERR_OFFSETS_TOO_SMALL; a = (int64_t)(nv + cnt + 2); break; }
+                if (o + len > pg.dst_cap) { st = PQD_ERR_DST_TOO_SMALL; a = (int64_t)(o + len); break; }
+                if (p + 4 + len > avail) { // bytes not all staged
+                    if (cnt == 0) { v_pos[0] = (uint32_t)(p + 4); v_len[0] = (uint32_t)len; cnt = 1; p += 4 + len; o += len; big = 1; }
+                    break;
+                }
+                v_pos[cnt] = (uint32_t)(p + 4);
+                v_len[cnt] = (uint32_t)len;
+                cnt++;
+                p += 4 + len;
+                o += len;
+            }
+            ctl[0] = (uint32_t)cnt; ctl[1] = (uint32_t)st; ctl[2] = (uint32_t)a; ctl[3] = (uint32_t)((uint64_t)a >> 32);
+            ctl[4] = big; ctl[5] = (uint32_t)p;
+        }
+        __syncthreads();
+        const uint32_t cnt = ctl[0];
+        const bool big = ctl[4] != 0;
+        // offsets of the batch, then the bytes
+        uint64_t o = out;
+        for (uint32_t v = 0; v < cnt; v++) {
+            const uint32_t len = v_len[v], pos = v_pos[v];
+            if (lane == 0) offsets[nv + v] = (uint32_t)o;
+            if (big) {
+                for (uint64_t b = lane; b < len; b += WT) dst[o + b] = src[i + pos + b];
+            } else {
+                for (uint32_t b = lane; b < len; b += WT) dst[o + b] = stage[pos + b];
+            }
+            o += len;
+        }
+        out = o;
+        nv += cnt;
+        status = (int32_t)ctl[1];
+        arg = (int64_t)(((uint64_t)ctl[3] << 32) | ctl[2]);
+        i += big ? (uint64_t)v_pos[0] + v_len[0] : ctl[5];
+        __syncthreads();
+    }
+    if (lane == 0) {
+        if (status == PQD_OK) {
+            if (nv + 1 > pg.offsets_cap) { status = PQD_ERR_OFFSETS_TOO_SMALL; arg = (int64_t)(nv + 1); }
+            else offsets[nv] = (uint32_t)out;
+        }
+        finish(res, status, arg, nv, out, status == PQD_OK ? n : i);
+    }
+}
+
+// ------------------------------------------- DELTA_LENGTH_BYTE_ARRAY scan --
+
+// Maps the result of a length stream that failed.  A stream that only ran out
+// of room asks for more offsets (BYTE_ARRAY) or more output (FIXED_LEN).
+__device__ inline void lengths_failed(DevResult* res, const DevResult& r, const DevPage& pg) {
+    int32_t st = r.status;
+    int64_t arg = r.arg;
+    if (st == PQD_ERR_DST_TOO_SMALL) {
+        const uint64_t total = (uint64_t)r.arg / 4;
+        if (pg.kind == PQD_KIND_BYTE_ARRAY) { st = PQD_ERR_OFFSETS_TOO_SMALL; arg = (int64_t)(total + 1); }
+        else arg = (int64_t)(total * (uint64_t)(pg.bit_width > 0 ? pg.bit_width : 1));
+    }
+    finish(res, st, arg, 0, 0, r.consumed);
+}
+
+// length_byte_array_purego.go:11-24 on the lengths the chained item left in
+// the offsets buffer: exclusive prefix sum in place, the first negative length
+// is an error.  One workgroup per page; the copy of the bytes is a second
+// kernel so that it can use the whole chip.
+__global__ __launch_bounds__(MT) void dlba_offsets_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                          const uint32_t* __restrict__ items) {
+    __shared__ uint32_t wsum[MT / 64];
+    __shared__ unsigned long long first_bad;
+    const uint32_t item = items[blockIdx.x];
+    const DevPage& pg = pages[item];
+    DevResult* res = &results[item];
+    const DevResult lr = results[pg.chain];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (lr.status != PQD_OK) {
+        if (tid == 0) lengths_failed(res, lr, pg);
+        return;
+    }
+    const uint64_t nl = lr.out_values;
+    if (nl + 1 > pg.offsets_cap) {
+        if (tid == 0) finish(res, PQD_ERR_OFFSETS_TOO_SMALL, (int64_t)(nl + 1), 0, 0, lr.consumed);
+        return;
+    }
+    gptr<uint32_t> off = as_global(pg.offsets);
+    if (tid == 0) first_bad = ~0ull;
+    __syncthreads();
+    uint32_t carry = 0;
+    for (uint64_t base = 0; base < nl; base += (uint64_t)MT * 4) {
+        const uint64_t k = base + tid * 4;
+        uint32_t v[4] = {0, 0, 0, 0};
+        for (uint32_t e = 0; e < 4; e++)
+            if (k + e < nl) {
+                v[e] = off[k + e];
+                if ((int32_t)v[e] < 0) atomicMin(&first_bad, ((unsigned long long)(k + e) << 32) | v[e]);
+            }
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+        uint32_t x = mine;
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t y = __shfl_up(x, d);
+            if ((int)lane >= d) x += y;
+        }
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint32_t before = carry, all = 0;
+        for (uint32_t w = 0; w < MT / 64; w++) {
+            if (w < wave) before += wsum[w];
+            all += wsum[w];
+        }
+        uint32_t o = before + x - mine;
+        for (uint32_t e = 0; e < 4; e++)
+            if (k + e < nl) { off[k + e] = o; o += v[e]; }
+        carry += all;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const unsigned long long bad = first_bad;
+        const uint64_t rest = pg.src_len - lr.consumed;
+        if (bad != ~0ull) {
+            finish(res, PQD_ERR_NEGATIVE_LENGTH, (int64_t)(int32_t)(uint32_t)bad, 0, 0, lr.consumed);
+        } else {
+            off[nl] = carry;
+            if ((uint64_t)carry > rest) finish(res, PQD_ERR_LENGTH_OUT_OF_BOUNDS, (int64_t)carry, nl, 0, lr.consumed);
+            else if ((uint64_t)carry > pg.dst_cap) finish(res, PQD_ERR_DST_TOO_SMALL, (int64_t)carry, nl, 0, lr.consumed);
+            else finish(res, PQD_OK, 0, nl, carry, lr.consumed + carry);
+        }
+    }
+}
+
+// length_byte_array.go:58-60: the values are the bytes after the lengths.
+__global__ __launch_bounds__(MT) void dlba_copy_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                       const uint32_t* __restrict__ items) {
+    const uint32_t item = items[blockIdx.x];
+    const DevPage& pg = pages[item];
+    const DevResult r = results[item];
+    if (r.status != PQD_OK) return;
+    copy_span(as_global(pg.dst), as_global(pg.src) + (r.consumed - r.out_bytes), r.out_bytes);
+}
+
+// ------------------------------------------------------- DELTA_BYTE_ARRAY --
+
+constexpr uint32_t LAST_CAP = 2048;  // leading bytes of the previous value kept in LDS
+constexpr uint32_t DSTAGE = 8192;    // suffix bytes staged per round
+
+__device__ inline uint64_t wave_excl_scan64(uint64_t v, uint32_t lane, uint64_t* total) {
+    uint64_t x = v;
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t y = __shfl_up(x, d);
+        if ((int)lane >= d) x += y;
+    }
+    *total = __shfl(x, 63);
+    return x - v;
+}
+
+// byte_array_purego.go:5-63.  Value k is the first prefix[k] bytes of value
+// k-1 followed by suffix[k] bytes of the data section, so values are produced
+// in order, one wavefront per page: lengths are checked and turned into source
+// and output positions 64 values at a time, the suffix bytes of those values
+// are staged in LDS with coalesced loads, and the running "previous value"
+// lives in LDS too, where a new value only overwrites the bytes after its
+// prefix.
+__global__ __launch_bounds__(WT) void dba_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                 const uint32_t* __restrict__ items) {
+    __shared__ __attribute__((aligned(16))) uint8_t stage[DSTAGE];
+    __shared__ __attribute__((aligned(16))) uint8_t last[LAST_CAP];
+    const uint32_t item = items[blockIdx.x];
+    const DevPage& pg = pages[item];
+    DevResult* res = &results[item];
+    const int32_t s_item = pg.chain, p_item = pages[s_item].chain;
+    const DevResult rp = results[p_item], rs = results[s_item];
+    const uint32_t lane = threadIdx.x;
+    const bool with_offsets = pg.kind == PQD_KIND_BYTE_ARRAY;
+    if (!with_offsets && (pg.bit_width < 0 || (uint32_t)pg.bit_width > MAX_FLBA)) { // byte_array.go:149-151
+        if (lane == 0) finish(res, PQD_ERR_INVALID_ARGUMENT, pg.bit_width, 0, 0, 0);
+        return;
+    }
+    if (rp.status != PQD_OK) { if (lane == 0) lengths_failed(res, rp, pg); return; }
+    if (rs.status != PQD_OK) { if (lane == 0) lengths_failed(res, rs, pg); return; }
+    const uint64_t np = rp.out_values, ns = rs.out_values;
+    if (np != ns) { // byte_array.go:142-144
+        if (lane == 0) finish(res, PQD_ERR_PREFIX_SUFFIX_MISMATCH, (int64_t)((np << 32) | (ns & 0xffffffffull)), 0, 0, rs.consumed);
+        return;
+    }
+    gptr<const int32_t> prefix = (gptr<const int32_t>)as_global(pg.lengths);
+    gptr<const int32_t> suffix = (gptr<const int32_t>)as_global(pg.lengths2);
+    gptr<const uint8_t> data = as_global(pg.src) + rs.consumed;
+    const uint64_t data_total = pg.src_len - rs.consumed;
+    gptr<uint8_t> dst = as_global(pg.dst);
+    gptr<uint32_t> offsets = as_global(pg.offsets);
+
+    uint64_t src_base = 0, out_base = 0, done = 0;
+    uint64_t prev_len = 0, prev_out = 0; // the previous value: its length and where it went
+    int32_t status = PQD_OK;
+    int64_t arg = 0;
+    while (done < ns && status == PQD_OK) {
+        const uint64_t k = done + lane;
+        const bool valid = k < ns;
+        const int64_t pl = valid ? prefix[k] : 0, sl = valid ? suffix[k] : 0;
+        const uint64_t s_pos = sl > 0 ? (uint64_t)sl : 0, p_pos = pl > 0 ? (uint64_t)pl : 0;
+        uint64_t s_tot, v_tot;
+        const uint64_t s_off = src_base + wave_excl_scan64(s_pos, lane, &s_tot);
+        const uint64_t o_off = out_base + wave_excl_scan64(p_pos + s_pos, lane, &v_tot);
+        uint64_t before = __shfl_up(p_pos + s_pos, 1);
+        if (lane == 0) before = prev_len;
+        int32_t err = PQD_OK;
+        int64_t err_arg = 0;
+        if (valid) {
+            if (sl < 0) { err = PQD_ERR_NEGATIVE_LENGTH; err_arg = sl; }
+            else if ((uint64_t)sl > data_total - s_off) { err = PQD_ERR_LENGTH_OUT_OF_BOUNDS; err_arg = sl; }
+            else if (pl < 0) { err = PQD_ERR_NEGATIVE_PREFIX; err_arg = pl; }
+            else if ((uint64_t)pl > before) { err = PQD_ERR_PREFIX_OUT_OF_BOUNDS; err_arg = pl; }
+            else if (with_offsets && k + 2 > pg.offsets_cap) { err = PQD_ERR_OFFSETS_TOO_SMALL; err_arg = (int64_t)(ns + 1); }
+            else if (o_off + p_pos + s_pos > pg.dst_cap) { err = PQD_ERR_DST_TOO_SMALL; err_arg = -1; }
+        }
+        const unsigned long long bad = __ballot(err != PQD_OK);
+        const unsigned long long live = __ballot(valid);
+        uint32_t m = (uint32_t)__popcll(live);
+        if (bad) {
+            const uint32_t first = (uint32_t)__builtin_ctzll(bad);
+            m = first;
+            status = __shfl(err, first);
+            arg = __shfl(err_arg, first);
+        }
+        // values [done, done + m) are good; the staged span may cut the round shorter
+        uint32_t taken = 0;
+        while (taken < m) {
+            const uint64_t span0 = __shfl(s_off, taken);
+            // how many values from `taken` on have their suffix bytes inside one stage?
+            const bool fits = lane >= taken && lane < m && (s_off + s_pos - span0) <= DSTAGE;
+            const unsigned long long fmask = __ballot(fits) >> taken;
+            uint32_t cnt = fmask == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fmask);
+            const bool single_big = cnt == 0; // one value whose suffix alone exceeds the stage
+            if (single_big) cnt = 1;
+            const uint64_t span1 = __shfl(s_off + s_pos, taken + cnt - 1);
+            if (!single_big) {
+                stage_fill(stage, data + span0, span1 - span0, lane);
+            }
+            __syncthreads();
+            for (uint32_t v = taken; v < taken + cnt; v++) {
+                const uint64_t p_v = __shfl(p_pos, v), s_v = __shfl(s_pos, v);
+                const uint64_t so = __shfl(s_off, v), oo = __shfl(o_off, v);
+                if (with_offsets && lane == 0) offsets[done + v] = (uint32_t)oo;
+                const uint64_t len = p_v + s_v;
+                // prefix bytes: from the LDS copy of the previous value, beyond it from where that value went
+                if (p_v > LAST_CAP) {
+                    __threadfence(); // the previous value's stores must be readable
+                    for (uint64_t b = LAST_CAP + lane; b < p_v; b += WT) dst[oo + b] = dst[prev_out + b];
+                }
+                // suffix bytes into the LDS copy (as far as it reaches) ...
+                if (!single_big) {
+                    for (uint64_t b = lane; b < s_v && p_v + b < LAST_CAP; b += WT) last[p_v + b] = stage[so - span0 + b];
+                } else {
+                    for (uint64_t b = lane; b < s_v && p_v + b < LAST_CAP; b += WT) last[p_v + b] = data[so + b];
+                }
+                __syncthreads();
+                // ... the value's first bytes from the LDS copy ...
+                const uint64_t head = len < LAST_CAP ? len : LAST_CAP;
+                for (uint64_t b = lane; b < head; b += WT) dst[oo + b] = last[b];
+                // ... and the suffix bytes that did not pass through it
+                if (len > LAST_CAP) {
+                    const uint64_t from = p_v > LAST_CAP ? 0 : LAST_CAP - p_v; // first suffix byte not in `last`
+                    if (!single_big) {
+                        for (uint64_t b = from + lane; b < s_v; b += WT) dst[oo + p_v + b] = stage[so - span0 + b];
+                    } else {
+                        for (uint64_t b = from + lane; b < s_v; b += WT) dst[oo + p_v + b] = data[so + b];
+                    }
+                }
+                prev_len = len;
+                prev_out = oo;
+                __syncthreads();
+            }
+            taken += cnt;
+        }
+        if (m > 0) {
+            src_base = __shfl(s_off + s_pos, m - 1);
+            out_base = __shfl(o_off + p_pos + s_pos, m - 1);
+        }
+        done += m;
+        if (status != PQD_OK) break;
+    }
+    if (status == PQD_ERR_DST_TOO_SMALL) {
+        // report the whole size so that one retry suffices
+        uint64_t need = 0;
+        for (uint64_t k = lane; k < ns; k += WT) {
+            const int32_t p = prefix[k], s = suffix[k];
+            need += (uint64_t)(p > 0 ? p : 0) + (uint64_t)(s > 0 ? s : 0);
+        }
+        for (int d = 32; d > 0; d >>= 1) need += __shfl_down(need, d);
+        arg = (int64_t)__shfl(need, 0);
+    }
+    if (lane == 0) {
+        if (status == PQD_OK && with_offsets) {
+            if (done + 1 > pg.offsets_cap) { status = PQD_ERR_OFFSETS_TOO_SMALL; arg = (int64_t)(done + 1); }
+            else offsets[done] = (uint32_t)out_base;
+        }
+        finish(res, status, arg, done, out_base, status == PQD_OK ? rs.consumed + src_base : rs.consumed);
+    }
+}
+
+// Wrapping int32 sum of a decoded length stream (delta.go:28-33), for
+// EstimateDecodeByteArraySize (length_byte_array.go:65-70, byte_array.go:176-183).
+__global__ __launch_bounds__(MT) void sum_lengths_kernel(const int32_t* __restrict__ v, uint64_t n, uint32_t* __restrict__ out) {
+    __shared__ uint32_t part[MT / 64];
+    uint32_t s = 0;
+    for (uint64_t k = threadIdx.x; k < n; k += MT) s += (uint32_t)v[k];
+    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < MT / 64; w++) t += part[w];
+        *out += t;
+    }
+}
+
+uint32_t tile_slots(uint64_t max_units, uint64_t per_tile) {
+    uint64_t t = (max_units + per_tile - 1) / per_tile;
+    if (t < 1) t = 1;
+    return (uint32_t)(t > 4096 ? 4096 : t);
+}
+
+} // namespace
+
+void launch_bitpacked(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_values,
+                      hipStream_t stream) {
+    if (n_items == 0) return;
+    hipLaunchKernelGGL(bitpacked_kernel, dim3(n_items, tile_slots(max_values, MT * 16)), dim3(MT), 0, stream, pages, results, items);
+}
+
+void launch_bss(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_bytes,
+                hipStream_t stream) {
+    if (n_items == 0) return;
+    hipLaunchKernelGGL(bss_kernel, dim3(n_items, tile_slots(max_bytes / 4, MT * 4)), dim3(MT), 0, stream, pages, results, items);
+}
+
+void launch_plain_fixed(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_bytes,
+                        hipStream_t stream) {
+    if (n_items == 0) return;
+    hipLaunchKernelGGL(plain_fixed_kernel, dim3(n_items, tile_slots(max_bytes, MT * 64)), dim3(MT), 0, stream, pages, results, items);
+}
+
+void launch_plain_byte_array(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
+                             hipStream_t stream) {
+    if (n_items == 0) return;
+    hipLaunchKernelGGL(plain_byte_array_kernel, dim3(n_items), dim3(WT), 0, stream, pages, results, items);
+}
+
+void launch_dlba(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_bytes,
+                 hipStream_t stream) {
+    if (n_items == 0) return;
+    hipLaunchKernelGGL(dlba_offsets_kernel, dim3(n_items), dim3(MT), 0, stream, pages, results, items);
+    hipLaunchKernelGGL(dlba_copy_kernel, dim3(n_items, tile_slots(max_bytes, MT * 64)), dim3(MT), 0, stream, pages, results, items);
+}
+
+void launch_dba(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, hipStream_t stream) {
+    if (n_items == 0) return;
+    hipLaunchKernelGGL(dba_kernel, dim3(n_items), dim3(WT), 0, stream, pages, results, items);
+}
+
+void launch_sum_lengths(const int32_t* v, uint64_t n, uint32_t* out, hipStream_t stream) {
+    hipLaunchKernelGGL(sum_lengths_kernel, dim3(1), dim3(MT), 0, stream, v, n, out);
+}
+
+} // namespace pqd

@@ -80,7 +80,8 @@ enum Family : int32_t {
     FAM_PLAIN_BYTE_ARRAY = 8,
     FAM_DLBA = 9,
     FAM_DBA = 10,
-    FAM_ERROR = 11      // rejected on the host; status already set
+    FAM_ERROR = 11,     // rejected on the host; status already set
+    FAM_DELTA32_CHAINED = 12 // a length stream that starts where another item's stream ended
 };
 
 // Pointers read out of a descriptor are generic to the compiler, which then
@@ -108,6 +109,19 @@ void launch_rle_index(const DevPage* pages, DevResult* results, const uint32_t* 
                       hipStream_t stream);
 void launch_rle_expand(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
                        const uint64_t* tile_prefix, uint64_t n_tiles, hipStream_t stream);
+
+void launch_bitpacked(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_values,
+                      hipStream_t stream);
+void launch_bss(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_bytes,
+                hipStream_t stream);
+void launch_plain_fixed(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_bytes,
+                        hipStream_t stream);
+void launch_plain_byte_array(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
+                             hipStream_t stream);
+void launch_dlba(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_bytes,
+                 hipStream_t stream);
+void launch_dba(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, hipStream_t stream);
+void launch_sum_lengths(const int32_t* v, uint64_t n, uint32_t* out, hipStream_t stream);
 
 constexpr uint32_t RLE_TILE = 2048; // output values per expand workgroup
 

@@ -1,0 +1,339 @@
+"""GPU parity: BIT_PACKED levels, BYTE_STREAM_SPLIT, PLAIN, DELTA_LENGTH_BYTE_ARRAY and
+DELTA_BYTE_ARRAY through the C ABI against the CPU checker.
+
+Mirrors the reference's encoding tests (encoding/encoding_test.go tables and
+round trips, encoding/bitpacked/bitpacked_test.go, the fuzz seeds under
+encoding/delta/testdata, the parquet test files) with the GPU kernels in the
+place of the Go decoders.  Bit exact.
+"""
+import numpy as np
+import pytest
+
+from oracle import pqoracle as O
+from tests import fixtures as F
+from tests import refdata as R
+from tests.gpu_util import assert_same, decode, pkg, spec
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_byte_array(out, want, what):
+    assert out.status == want.status, f"{what}: status {out.status} != {want.status} (args {out.arg}, {want.arg})"
+    if want.status != 0:
+        assert out.arg == want.arg, f"{what}: status arg {out.arg} != {want.arg}"
+        return
+    assert out.out_values == want.n_values, f"{what}: {out.out_values} values, want {want.n_values}"
+    assert out.data.tobytes() == want.values.tobytes(), f"{what}: bytes differ"
+    assert np.array_equal(out.offsets[: want.n_values + 1], want.offsets), f"{what}: offsets differ"
+    assert out.consumed == want.consumed, f"{what}: consumed {out.consumed} != {want.consumed}"
+
+
+def _strings(rng, n, lo=0, hi=21):
+    return [bytes(rng.integers(0, 256, size=int(k), dtype=np.uint8)) for k in rng.integers(lo, hi + 1, size=n)]
+
+
+def _urls(rng, n):
+    # docs/delta-byte-array-prefix.md:89-92: a few hot prefixes and a numeric tail
+    heads = [b"https://www.example.com/catalog/items/", b"https://cdn.example.org/static/img/", b"http://a.io/",
+             b"https://api.example.net/v2/accounts/transactions/history/", b"ftp://files.example.com/pub/"]
+    out = [heads[int(h)] + b"%08d" % int(t) for h, t in zip(rng.integers(0, 5, size=n), rng.integers(0, 10**8, size=n))]
+    return sorted(out)
+
+
+# ---------------------------------------------------------------- BIT_PACKED --
+
+def test_bitpacked_levels():
+    P = pkg()
+    cases = []
+    for bw, values, enc in R.BITPACKED_KATS:  # bitpacked_test.go:18-56
+        cases.append((f"kat-bw{bw}", enc, bw))
+    rng = np.random.default_rng(3)
+    for bw in range(0, 9):
+        for n in (0, 1, 7, 8, 9, 63, 64, 65, 1000, 4097, 70001):
+            v = rng.integers(0, 1 << bw, size=n, dtype=np.uint8) if bw else np.zeros(n, np.uint8)
+            cases.append((f"bw{bw}-n{n}", O.bitpacked_encode_levels(v, bw), bw))
+    for k, levels in enumerate(R.LEVELS_TESTS):
+        v = np.array(levels, np.uint8)
+        bw = R.max_len(levels, 8)
+        cases.append((f"table{k}", O.bitpacked_encode_levels(v, bw), bw))
+    outs = decode([spec(P.ENC.BIT_PACKED, P.KIND.LEVELS, enc, bit_width=bw, misalign=k % 16) for k, (_, enc, bw) in enumerate(cases)])
+    for (label, enc, bw), out in zip(cases, outs):
+        assert_same(out, O.bitpacked_decode_levels(enc, bw), np.uint8, label)
+    # the known bytes decode to the known levels
+    for (bw, values, enc), out in zip(R.BITPACKED_KATS, outs):
+        assert list(out.data[: len(values)]) == values
+
+
+# --------------------------------------------------------- BYTE_STREAM_SPLIT --
+
+def test_byte_stream_split():
+    P = pkg()
+    rng = np.random.default_rng(4)
+    cases = []
+    for k, t in enumerate(R.FLOAT_TESTS):
+        cases.append((f"float{k}", P.KIND.FLOAT, 4, np.array(t, np.float32).tobytes()))
+    for k, t in enumerate(R.DOUBLE_TESTS):
+        cases.append((f"double{k}", P.KIND.DOUBLE, 8, np.array(t, np.float64).tobytes()))
+    for k, t in enumerate(R.INT32_TESTS):
+        cases.append((f"int32-{k}", P.KIND.INT32, 4, np.array(t, np.int32).tobytes()))
+    for k, t in enumerate(R.INT64_TESTS):
+        cases.append((f"int64-{k}", P.KIND.INT64, 8, np.array(t, np.int64).tobytes()))
+    for n in (1, 2, 3, 4, 5, 255, 256, 257, 1023, 1024, 1025, 100003):
+        cases.append((f"f32-n{n}", P.KIND.FLOAT, 4, rng.standard_normal(n).astype(np.float32).tobytes()))
+        cases.append((f"f64-n{n}", P.KIND.DOUBLE, 8, rng.standard_normal(n).tobytes()))
+    for size, data in R.FLBA_TESTS:
+        cases.append((f"flba{size}", P.KIND.FIXED_LEN_BYTE_ARRAY, size, data))
+    for size in (3, 5, 12, 16, 33):
+        cases.append((f"flba{size}-rand", P.KIND.FIXED_LEN_BYTE_ARRAY, size, rng.integers(0, 256, size=size * 1001, dtype=np.uint8).tobytes()))
+    specs, wants = [], []
+    for k, (label, kind, size, plain) in enumerate(cases):
+        enc = O.bss_encode(plain, size)
+        specs.append(spec(P.ENC.BYTE_STREAM_SPLIT, kind, enc, bit_width=size if kind == P.KIND.FIXED_LEN_BYTE_ARRAY else 0, misalign=k % 16))
+        wants.append(O.bss_decode(enc, size, kind == P.KIND.FIXED_LEN_BYTE_ARRAY))
+    outs = decode(specs)
+    for (label, kind, size, plain), out, want in zip(cases, outs, wants):
+        assert_same(out, want, np.uint8, label)
+        assert out.data.tobytes() == plain, label  # round trip
+
+
+def test_byte_stream_split_errors():
+    P = pkg()
+    cases = [
+        ("f32-len5", P.KIND.FLOAT, 0, b"12345", 4, False),
+        ("f64-len12", P.KIND.DOUBLE, 0, b"123456789012", 8, False),
+        ("flba-size0", P.KIND.FIXED_LEN_BYTE_ARRAY, 0, b"1234", 0, True),
+        ("flba-size-neg", P.KIND.FIXED_LEN_BYTE_ARRAY, -3, b"1234", -3, True),
+        ("flba-size-big", P.KIND.FIXED_LEN_BYTE_ARRAY, 40000, b"1234", 40000, True),
+        ("flba-len7-size3", P.KIND.FIXED_LEN_BYTE_ARRAY, 3, b"1234567", 3, True),
+    ]
+    outs = decode([spec(P.ENC.BYTE_STREAM_SPLIT, kind, src, bit_width=bw) for _, kind, bw, src, _, _ in cases])
+    for (label, kind, bw, src, size, flba), out in zip(cases, outs):
+        assert_same(out, O.bss_decode(src, size, flba), np.uint8, label, values=False)
+    out = decode([spec(P.ENC.BYTE_STREAM_SPLIT, P.KIND.DOUBLE, bytes(800), dst_cap=100)], grow=False)[0]
+    assert out.status == P.STATUS.DST_TOO_SMALL and out.arg == 800
+
+
+# --------------------------------------------------------------------- PLAIN --
+
+def test_plain_fixed():
+    P = pkg()
+    rng = np.random.default_rng(5)
+    cases = []
+    for n in (0, 1, 3, 15, 16, 17, 31, 33, 4095, 4096, 4097, 300001):
+        cases.append((f"int32-n{n}", P.KIND.INT32, 0, 4, rng.integers(-2**31, 2**31 - 1, size=n, dtype=np.int32).tobytes(), False))
+        cases.append((f"int64-n{n}", P.KIND.INT64, 0, 8, rng.integers(-2**63, 2**63 - 1, size=n, dtype=np.int64).tobytes(), False))
+        cases.append((f"int96-n{n}", P.KIND.INT96, 0, 12, rng.integers(0, 256, size=12 * n, dtype=np.uint8).tobytes(), False))
+        cases.append((f"bool-n{n}", P.KIND.BOOLEAN, 1, 1, rng.integers(0, 256, size=n, dtype=np.uint8).tobytes(), False))
+    cases.append(("float", P.KIND.FLOAT, 0, 4, np.array(R.FLOAT_TESTS[3], np.float32).tobytes(), False))
+    cases.append(("double", P.KIND.DOUBLE, 0, 8, np.array(R.DOUBLE_TESTS[3], np.float64).tobytes(), False))
+    for size, data in R.FLBA_TESTS:
+        cases.append((f"flba{size}", P.KIND.FIXED_LEN_BYTE_ARRAY, size, size, data, True))
+    # errors: length not a multiple of the width, bad FIXED_LEN sizes
+    cases += [
+        ("int32-len5", P.KIND.INT32, 0, 4, b"12345", False),
+        ("int96-len13", P.KIND.INT96, 0, 12, b"1234567890123", False),
+        ("flba-size0", P.KIND.FIXED_LEN_BYTE_ARRAY, 0, 0, b"1234", True),
+        ("flba-len7-size3", P.KIND.FIXED_LEN_BYTE_ARRAY, 3, 3, b"1234567", True),
+    ]
+    outs = decode([spec(P.ENC.PLAIN, kind, src, bit_width=bw, misalign=(3 * k) % 16) for k, (_, kind, bw, _, src, _) in enumerate(cases)])
+    for (label, kind, bw, width, src, flba), out in zip(cases, outs):
+        want = O.plain_decode_fixed(src, width, flba)
+        assert_same(out, want, np.uint8, label, values=want.status == 0)
+    out = decode([spec(P.ENC.PLAIN, P.KIND.INT64, bytes(800), dst_cap=792)], grow=False)[0]
+    assert out.status == P.STATUS.DST_TOO_SMALL and out.arg == 800
+
+
+def test_plain_byte_array():
+    P = pkg()
+    rng = np.random.default_rng(6)
+    cases = [(f"table{k}", O.plain_encode_byte_array(v)) for k, v in enumerate(R.BYTE_ARRAY_TESTS)]
+    for n in (1, 2, 63, 64, 65, 129, 1000, 20000):
+        cases.append((f"rand-n{n}", O.plain_encode_byte_array(_strings(rng, n))))
+    cases.append(("urls", O.plain_encode_byte_array(_urls(rng, 5000))))
+    # records around the size of the staging buffer, and far above it
+    cases.append(("long", O.plain_encode_byte_array(_strings(rng, 40, 3000, 9000) + [b"x"] + _strings(rng, 3, 20000, 40000) + [b"tail"])))
+    cases.append(("empty-strings", O.plain_encode_byte_array([b""] * 300)))
+    full = O.plain_encode_byte_array(_strings(rng, 200))
+    for cut in (1, 3, 4, 5, len(full) // 2, len(full) - 1):
+        cases.append((f"cut{cut}", full[:cut]))
+    cases.append(("huge-length", b"\xff\xff\xff\x7fabc"))
+    outs = decode([spec(P.ENC.PLAIN, P.KIND.BYTE_ARRAY, enc, misalign=k % 16) for k, (_, enc) in enumerate(cases)])
+    for (label, enc), out in zip(cases, outs):
+        want = O.plain_decode_byte_array(enc)
+        _same_byte_array(out, want, label)
+        if want.status != 0:  # what was decoded before the failure is still handed back (plain.go:80-92)
+            assert out.out_values == want.n_values and out.data.tobytes() == want.values.tobytes(), label
+
+
+def test_plain_file_pages():
+    P = pkg()
+    items = [(r, a) for r, a in F.pages(kind=("v1", "v2", "dict"), encoding=(0,)) if r["physical_type"] in ("BYTE_ARRAY", "INT32", "INT64", "DOUBLE", "FLOAT", "INT96")]
+    assert items
+    kinds = {"BYTE_ARRAY": P.KIND.BYTE_ARRAY, "INT32": P.KIND.INT32, "INT64": P.KIND.INT64, "DOUBLE": P.KIND.DOUBLE,
+             "FLOAT": P.KIND.FLOAT, "INT96": P.KIND.INT96}
+    outs = decode([spec(P.ENC.PLAIN, kinds[r["physical_type"]], a["values"].tobytes(), misalign=k % 16) for k, (r, a) in enumerate(items)])
+    for (r, a), out in zip(items, outs):
+        if r["physical_type"] == "BYTE_ARRAY":
+            _same_byte_array(out, O.plain_decode_byte_array(a["values"]), F.page_id(r))
+        else:
+            assert_same(out, O.plain_decode_fixed(a["values"], F.WIDTH[r["physical_type"]]), np.uint8, F.page_id(r))
+        if r["kind"] != "dict" and "expected_values" in a:
+            assert out.data.tobytes() == np.ascontiguousarray(a["expected_values"]).tobytes(), F.page_id(r)
+
+
+# --------------------------------------------------- DELTA_LENGTH_BYTE_ARRAY --
+
+def test_delta_length_byte_array():
+    P = pkg()
+    rng = np.random.default_rng(7)
+    cases = [(f"table{k}", O.dlba_encode(v)) for k, v in enumerate(R.BYTE_ARRAY_TESTS)]
+    for n in R.QUICK_SIZES:
+        cases.append((f"rand-n{n}", O.dlba_encode(_strings(rng, n))))
+    cases.append(("urls", O.dlba_encode(_urls(rng, 30000))))
+    cases.append(("long", O.dlba_encode(_strings(rng, 50, 1000, 70000))))
+    outs = decode([spec(P.ENC.DELTA_LENGTH_BYTE_ARRAY, P.KIND.BYTE_ARRAY, enc, misalign=k % 16) for k, (_, enc) in enumerate(cases)])
+    for (label, enc), out in zip(cases, outs):
+        _same_byte_array(out, O.dlba_decode(enc), label)
+
+
+def test_delta_length_byte_array_errors():
+    P = pkg()
+    rng = np.random.default_rng(8)
+    full = O.dlba_encode(_strings(rng, 300))
+    cases = [("empty", b"")]
+    for cut in (1, 2, 3, 4, 5, 10, 100, len(full) // 2, len(full) - 1):
+        cases.append((f"cut{cut}", full[:cut]))
+    neg = O.delta_encode_int32(np.array([3, 4, -2, 5, -7], np.int32)) + b"abcdefghijkl"
+    cases.append(("negative-length", neg))
+    cases.append(("lengths-past-the-data", O.delta_encode_int32(np.array([3, 4, 50], np.int32)) + b"abcdefg"))
+    cases.append(("bad-header", bytes([0x7f, 0x04, 0x01, 0x00])))
+    outs = decode([spec(P.ENC.DELTA_LENGTH_BYTE_ARRAY, P.KIND.BYTE_ARRAY, enc, misalign=k % 16) for k, (_, enc) in enumerate(cases)])
+    for (label, enc), out in zip(cases, outs):
+        _same_byte_array(out, O.dlba_decode(enc), label)
+    # capacity negotiation
+    enc = O.dlba_encode([b"abc"] * 100)
+    out = decode([spec(P.ENC.DELTA_LENGTH_BYTE_ARRAY, P.KIND.BYTE_ARRAY, enc, offsets_cap=50)], grow=False)[0]
+    assert out.status == P.STATUS.OFFSETS_TOO_SMALL and out.arg == 101
+    out = decode([spec(P.ENC.DELTA_LENGTH_BYTE_ARRAY, P.KIND.BYTE_ARRAY, enc, offsets_cap=100)], grow=False)[0]
+    assert out.status == P.STATUS.OFFSETS_TOO_SMALL and out.arg == 101
+    out = decode([spec(P.ENC.DELTA_LENGTH_BYTE_ARRAY, P.KIND.BYTE_ARRAY, enc, dst_cap=299)], grow=False)[0]
+    assert out.status == P.STATUS.DST_TOO_SMALL and out.arg == 300
+    out = decode([spec(P.ENC.DELTA_LENGTH_BYTE_ARRAY, P.KIND.BYTE_ARRAY, enc, dst_cap=300, offsets_cap=101)], grow=False)[0]
+    assert out.status == 0 and out.data.tobytes() == b"abc" * 100
+
+
+# ----------------------------------------------------------- DELTA_BYTE_ARRAY --
+
+def test_delta_byte_array():
+    P = pkg()
+    rng = np.random.default_rng(9)
+    cases = [(f"table{k}", O.dba_encode(v)) for k, v in enumerate(R.BYTE_ARRAY_TESTS)]
+    for n in R.QUICK_SIZES:
+        cases.append((f"rand-n{n}", O.dba_encode(_strings(rng, n))))
+    cases.append(("urls", O.dba_encode(_urls(rng, 20000))))
+    cases.append(("sorted-words", O.dba_encode(sorted(_strings(rng, 5000, 0, 6)))))
+    # values longer than the part of the previous value kept on chip, sharing long prefixes
+    base = bytes(rng.integers(0, 256, size=9000, dtype=np.uint8))
+    long_vals = [base[: int(k)] + bytes([int(k) & 255]) * int(t) for k, t in zip(rng.integers(0, 9000, size=60), rng.integers(0, 12000, size=60))]
+    cases.append(("long", O.dba_encode(long_vals)))
+    cases.append(("long-sorted", O.dba_encode(sorted(long_vals))))
+    cases.append(("repeats", O.dba_encode([b"same value again"] * 700)))
+    outs = decode([spec(P.ENC.DELTA_BYTE_ARRAY, P.KIND.BYTE_ARRAY, enc, misalign=k % 16) for k, (_, enc) in enumerate(cases)])
+    for (label, enc), out in zip(cases, outs):
+        _same_byte_array(out, O.dba_decode(enc), label)
+
+
+def test_delta_byte_array_fixed_len():
+    P = pkg()
+    rng = np.random.default_rng(10)
+    cases = []
+    for size, data in R.FLBA_TESTS:
+        vals = [data[i: i + size] for i in range(0, len(data), size)]
+        cases.append((f"flba{size}", size, O.dba_encode(vals)))
+    vals = sorted(bytes(rng.integers(0, 4, size=16, dtype=np.uint8)) for _ in range(3000))
+    cases.append(("flba16-sorted", 16, O.dba_encode(vals)))
+    cases.append(("size-negative", -1, O.dba_encode([b"ab"])))
+    cases.append(("size-too-big", 40000, O.dba_encode([b"ab"])))
+    outs = decode([spec(P.ENC.DELTA_BYTE_ARRAY, P.KIND.FIXED_LEN_BYTE_ARRAY, enc, bit_width=size, misalign=k % 16)
+                   for k, (_, size, enc) in enumerate(cases)])
+    for (label, size, enc), out in zip(cases, outs):
+        want = O.dba_decode_flba(enc, size)
+        assert_same(out, want, np.uint8, label, values=want.status == 0)
+
+
+def test_delta_byte_array_errors_and_fuzz_seeds():
+    P = pkg()
+    rng = np.random.default_rng(11)
+    full = O.dba_encode(_urls(rng, 400))
+    cases = [("empty", b"")]
+    for cut in (1, 2, 3, 4, 5, 10, 100, len(full) // 3, len(full) // 2, len(full) - 1):
+        cases.append((f"cut{cut}", full[:cut]))
+    for k, (data, _) in enumerate(R.FUZZ_DELTA_BYTE_ARRAY):  # encoding/delta/testdata/fuzz/FuzzDeltaByteArray
+        cases.append((f"fuzz{k}", data))
+    d32 = lambda v: O.delta_encode_int32(np.array(v, np.int32))
+    cases += [
+        ("count-mismatch", d32([0, 1, 2]) + d32([3, 3]) + b"abcdef"),
+        ("negative-suffix", d32([0, 1]) + d32([3, -1]) + b"abcdef"),
+        ("suffix-past-the-data", d32([0, 1]) + d32([3, 9]) + b"abcdef"),
+        ("negative-prefix", d32([0, -1]) + d32([3, 2]) + b"abcdef"),
+        ("prefix-past-the-last-value", d32([0, 4]) + d32([3, 2]) + b"abcdef"),
+        ("first-prefix-nonzero", d32([1, 0]) + d32([3, 2]) + b"abcdef"),
+    ]
+    outs = decode([spec(P.ENC.DELTA_BYTE_ARRAY, P.KIND.BYTE_ARRAY, enc, misalign=k % 16) for k, (_, enc) in enumerate(cases)])
+    for (label, enc), out in zip(cases, outs):
+        want = O.dba_decode(enc)
+        _same_byte_array(out, want, label)
+        if want.status not in (0, 16, 18):  # the values before the failing one are handed back
+            assert out.out_values == want.n_values and out.data.tobytes() == want.values.tobytes(), label
+    enc = O.dba_encode([b"abc%d" % i for i in range(100)])
+    want = O.dba_decode(enc)
+    out = decode([spec(P.ENC.DELTA_BYTE_ARRAY, P.KIND.BYTE_ARRAY, enc, dst_cap=50)], grow=False)[0]
+    assert out.status == P.STATUS.DST_TOO_SMALL and out.arg == want.n_bytes
+    out = decode([spec(P.ENC.DELTA_BYTE_ARRAY, P.KIND.BYTE_ARRAY, enc, offsets_cap=60)], grow=False)[0]
+    assert out.status == P.STATUS.OFFSETS_TOO_SMALL and out.arg == 101
+
+
+def test_delta_byte_array_file_pages():
+    # pages of testdata/delta_byte_array.parquet & co; expected strings from pyarrow
+    P = pkg()
+    dba = list(F.pages(kind=("v1", "v2"), encoding=(7,)))
+    dlba = list(F.pages(kind=("v1", "v2"), encoding=(6,)))
+    assert dba
+    outs = decode([spec(P.ENC.DELTA_BYTE_ARRAY, P.KIND.BYTE_ARRAY, a["values"].tobytes(), misalign=k % 16) for k, (r, a) in enumerate(dba)] +
+                  [spec(P.ENC.DELTA_LENGTH_BYTE_ARRAY, P.KIND.BYTE_ARRAY, a["values"].tobytes(), misalign=k % 16) for k, (r, a) in enumerate(dlba)])
+    for (r, a), out in zip(dba + dlba, outs):
+        assert out.status == 0 and out.out_values == r["num_non_null"], F.page_id(r)
+        assert out.data.tobytes() == a["expected_values"].tobytes(), F.page_id(r)
+        assert np.array_equal(out.offsets[: out.out_values + 1], a["expected_offsets"]), F.page_id(r)
+
+
+def test_mixed_batch_all_families():
+    # one batch holding every encoding, as a row group's column chunks would
+    P = pkg()
+    rng = np.random.default_rng(12)
+    ints = np.cumsum(rng.integers(0, 1000, size=5000, dtype=np.int64))
+    strs = _urls(rng, 2000)
+    lv = rng.integers(0, 4, size=9000, dtype=np.uint8)
+    f64 = rng.standard_normal(4000)
+    specs = [
+        spec(P.ENC.DELTA_BINARY_PACKED, P.KIND.INT64, O.delta_encode_int64(ints)),
+        spec(P.ENC.DELTA_BYTE_ARRAY, P.KIND.BYTE_ARRAY, O.dba_encode(strs)),
+        spec(P.ENC.RLE, P.KIND.LEVELS, O.rle_encode_levels(lv, 2), bit_width=2),
+        spec(P.ENC.DELTA_LENGTH_BYTE_ARRAY, P.KIND.BYTE_ARRAY, O.dlba_encode(strs)),
+        spec(P.ENC.BYTE_STREAM_SPLIT, P.KIND.DOUBLE, O.bss_encode(f64.tobytes(), 8)),
+        spec(P.ENC.PLAIN, P.KIND.BYTE_ARRAY, O.plain_encode_byte_array(strs)),
+        spec(P.ENC.BIT_PACKED, P.KIND.LEVELS, O.bitpacked_encode_levels(lv, 2), bit_width=2),
+        spec(P.ENC.PLAIN, P.KIND.DOUBLE, f64.tobytes()),
+        spec(P.ENC.DELTA_BYTE_ARRAY, P.KIND.BYTE_ARRAY, O.dba_encode(strs[::-1])),
+    ]
+    outs = decode(specs)
+    assert all(o.status == 0 for o in outs), [o.status for o in outs]
+    assert np.array_equal(outs[0].data.view(np.int64), ints)
+    joined = b"".join(strs)
+    for k in (1, 3, 5):
+        assert outs[k].data.tobytes() == joined
+    assert np.array_equal(outs[2].data[:9000], lv)
+    assert outs[4].data.tobytes() == f64.tobytes()
+    assert np.array_equal(outs[6].data[:9000], lv)
+    assert outs[7].data.tobytes() == f64.tobytes()
+    assert outs[8].data.tobytes() == b"".join(strs[::-1])
