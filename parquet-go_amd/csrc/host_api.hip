@@ -164,12 +164,46 @@ int pqd_decode_fixed_len_byte_array(pqd_ctx* ctx, int encoding, int size, const 
 }
 
 int64_t pqd_estimate_decode_byte_array_size(pqd_ctx* ctx, int encoding, const uint8_t* src, uint64_t src_len) {
-    (void)ctx; (void)src;
-    // plain.go:106-108: PLAIN answers len(src); the DELTA encodings sum their
-    // length streams (length_byte_array.go:65-70, byte_array.go:176-183), which
-    // needs a decode of those streams -- answered by the device path below.
+    // plain.go:106-108: PLAIN answers len(src).  The DELTA encodings sum their length
+    // streams with wrapping int32 arithmetic (delta.go:28-33; length_byte_array.go:65-70,
+    // byte_array.go:176-183): the streams are decoded and summed on the device.
     if (encoding == PQD_ENC_PLAIN) return (int64_t)src_len;
-    return 0;
+    if (encoding != PQD_ENC_DELTA_LENGTH_BYTE_ARRAY && encoding != PQD_ENC_DELTA_BYTE_ARRAY) return 0;
+    if (ctx == nullptr || (src == nullptr && src_len > 0)) return 0;
+    if (hipSetDevice(ctx->device) != hipSuccess) return 0;
+    DevMem dsrc, dsum;
+    if (!dsrc.alloc(src_len + 32) || !dsum.alloc(16)) return 0;
+    if (src_len && hipMemcpy(dsrc.p, src, src_len, hipMemcpyHostToDevice) != hipSuccess) return 0;
+    const int streams = encoding == PQD_ENC_DELTA_BYTE_ARRAY ? 2 : 1;
+    int64_t total = 0;
+    uint64_t at = 0;
+    for (int k = 0; k < streams; k++) {
+        uint64_t cap = 4096;
+        pqd_page p;
+        DevMem dlen;
+        for (int attempt = 0; attempt < 2; attempt++) {
+            if (dlen.p) { (void)hipFree(dlen.p); dlen.p = nullptr; }
+            if (!dlen.alloc(cap + 32)) return 0;
+            std::memset(&p, 0, sizeof p);
+            p.src = static_cast<uint8_t*>(dsrc.p) + at; p.src_len = src_len - at;
+            p.dst = dlen.p; p.dst_cap = cap;
+            p.num_values = -1;
+            p.encoding = PQD_ENC_DELTA_BINARY_PACKED; p.kind = PQD_KIND_INT32;
+            if (pqd_decode_batch(ctx, &p, 1, nullptr) != PQD_OK) return 0;
+            if (p.status != PQD_ERR_DST_TOO_SMALL) break;
+            cap = (uint64_t)p.status_arg;
+        }
+        if (p.status == PQD_ERR_DST_TOO_SMALL) return 0;
+        uint32_t sum = 0;
+        if (hipMemset(dsum.p, 0, 4) != hipSuccess) return 0;
+        if (p.out_values > 0) {
+            launch_sum_lengths(static_cast<const int32_t*>(dlen.p), p.out_values, static_cast<uint32_t*>(dsum.p), nullptr);
+            if (hipMemcpy(&sum, dsum.p, 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
+        }
+        total += (int64_t)(int32_t)sum;
+        at += p.consumed < src_len - at ? p.consumed : src_len - at;
+    }
+    return total;
 }
 
 int pqd_can_decode_in_place(int encoding) {
