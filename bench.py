@@ -199,25 +199,26 @@ def build_rle_dict_workload(pkg, ctx, device, seed, n_pages, values_per_page, di
     return wl
 
 
-def time_steps(torch, wl, stream, steps, warmup, dist=None):
-    for _ in range(warmup):
-        wl.launch(stream)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-    t0 = time.perf_counter()
-    for a, b in ev:
+def time_steps(S, torch, wl, stream, steps, warmup, dist=None):
+    """Wall seconds of exactly `steps` launches (barrier + synchronize on both sides) and the
+    per-launch kernel time from HIP events on the stream the kernels are launched on."""
+    ev = []
+    warm = {"left": warmup}
+
+    def step():
+        if warm["left"] > 0:
+            warm["left"] -= 1
+            wl.launch(stream)
+            return
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         wl.launch(stream)
         b.record()
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
+        ev.append((a, b))
+
+    wall = S.timed_region(step, steps, warmup, torch.cuda.synchronize, dist.barrier if dist is not None else None)
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    assert len(kernel_ms) == steps
     return wall, kernel_ms
 
 
@@ -261,6 +262,7 @@ def main():
     import torch
     import __graft_entry__ as entry
     pkg = entry.load_package()
+    from parquet_go_amd import sharding as S
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -279,7 +281,12 @@ def main():
     unique = min(args.unique_pages, args.pages)
     while args.pages % unique:
         unique -= 1
-    wl = build_delta_workload(pkg, ctx, device, rank, args.pages, args.values_per_page, unique)
+    # Row groups of `unique` pages each, dealt round robin over the ranks; every rank holds
+    # args.pages // unique of them (weak scaling), seeded by the first row group it owns.
+    n_row_groups = args.pages // unique
+    mine = S.row_groups_of(rank, world, world * n_row_groups)
+    assert len(mine) == n_row_groups
+    wl = build_delta_workload(pkg, ctx, device, mine[0], args.pages, args.values_per_page, unique)
 
     # correctness of what is being timed: every distinct page and its last replica
     wl.launch(stream)
@@ -292,14 +299,10 @@ def main():
                 if not np.array_equal(got, wl.expect[k]):
                     raise RuntimeError(f"page {slot} decoded wrong")
 
-    wall, kernel_ms = time_steps(torch, wl, stream, args.steps, args.warmup, dist)
-    t = torch.tensor([wall], dtype=torch.float64, device=f"cuda:{device}")
-    if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    wall_max = float(t.item())
+    wall, kernel_ms = time_steps(S, torch, wl, stream, args.steps, args.warmup, dist)
+    wall_max = S.max_over_ranks(wall, dist, f"cuda:{device}")
     ms_per_step = wall_max / args.steps * 1e3
-    decoded_gb = wl.decoded_bytes * world / 1e9
-    value = decoded_gb / (wall_max / args.steps)
+    value = S.whole_job_rate(wl.decoded_bytes / 1e9, world, wall_max / args.steps)
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
     achieved = wl.algorithmic_bytes / avg_kernel_s / 1e9
 
@@ -338,7 +341,7 @@ def main():
             for k in (0, c1.n_pages - 1):
                 if not np.array_equal(out[k].cpu().numpy(), c1.dictionary[c1.expect_idx[k]]):
                     raise RuntimeError("RLE_DICTIONARY page decoded wrong")
-        w1, k1 = time_steps(torch, c1, stream, max(args.steps, 20), args.warmup, None)
+        w1, k1 = time_steps(S, torch, c1, stream, max(args.steps, 20), args.warmup, None)
         s1 = w1 / max(args.steps, 20)
         a1 = c1.algorithmic_bytes / (float(np.mean(k1)) / 1e3) / 1e9
         result["extra"] = {"rle_dictionary_int64": {
