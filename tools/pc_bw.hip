@@ -15,7 +15,7 @@ __device__ inline void glds16(uint32_t lds_dst, const uint8_t* gsrc) {
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
 
-template <int DEPTH, bool IL = false, bool BAR = true>
+template <int DEPTH, bool IL = false, bool BAR = true, int Q = 4>
 __global__ __launch_bounds__(320) void pc(uint8_t* out, const uint8_t* in, int steps, int load_every) {
     __shared__ u32x4 ring[4][256];
     gp o = (gp)(out + (size_t)blockIdx.x * steps * 8192);
@@ -27,14 +27,14 @@ __global__ __launch_bounds__(320) void pc(uint8_t* out, const uint8_t* in, int s
     int issued = 0;
     if (loader) {
         for (; issued < DEPTH; issued++)
-            for (int q = 0; q < 4; q++)
+            for (int q = 0; q < Q; q++)
                 glds16(__builtin_amdgcn_readfirstlane(ring_lds + (issued & 3) * 4096 + q * 1024), src + (size_t)issued * 4096 + q * 1024 + l * 16);
     }
     for (int s = 0; s < steps; s++) {
         if (loader && s % load_every == 0) {
             // the oldest outstanding chunk has landed once at most (DEPTH-1)*4 loads are in flight
-            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((DEPTH - 1) * 4) : "memory");
-            for (int q = 0; q < 4; q++)
+            asm volatile("s_waitcnt vmcnt(%0)" :: "n"((DEPTH - 1) * Q) : "memory");
+            for (int q = 0; q < Q; q++)
                 glds16(__builtin_amdgcn_readfirstlane(ring_lds + (issued & 3) * 4096 + q * 1024), (IL ? in + ((size_t)issued * gridDim.x + blockIdx.x) * 4096 : src + (size_t)issued * 4096) + q * 1024 + l * 16);
             issued++;
         }
@@ -48,18 +48,18 @@ __global__ __launch_bounds__(320) void pc(uint8_t* out, const uint8_t* in, int s
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
-template <int DEPTH, bool IL = false, bool BAR = true>
+template <int DEPTH, bool IL = false, bool BAR = true, int Q = 4>
 void run(uint8_t* out, const uint8_t* in, int g, int steps, int load_every, hipEvent_t a, hipEvent_t b) {
     float best = 1e9;
     for (int rep = 0; rep < 5; rep++) {
         hipEventRecord(a);
-        pc<DEPTH, IL, BAR><<<g, 320>>>(out, in, steps, load_every);
+        pc<DEPTH, IL, BAR, Q><<<g, 320>>>(out, in, steps, load_every);
         hipEventRecord(b);
         hipEventSynchronize(b);
         float ms; hipEventElapsedTime(&ms, a, b);
         if (rep && ms < best) best = ms;
     }
-    printf("%s %s loader wave, depth %d, 4 KiB every %d steps, wgs %4d: %.1f us  written %.0f GB/s\n", IL ? "interleaved" : "streams    ", BAR ? "barrier/step" : "no barrier  ", DEPTH, load_every, g, best * 1e3,
+    printf("%s %s loader wave, depth %d, %d KiB every %d steps, wgs %4d: %.1f us  written %.0f GB/s\n", IL ? "interleaved" : "streams    ", BAR ? "barrier/step" : "no barrier  ", DEPTH, Q, load_every, g, best * 1e3,
            (double)g * steps * 8192 / best / 1e6);
 }
 
@@ -72,10 +72,12 @@ int main() {
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     for (int g : {2048}) {
-        run<2, false, true>(out, in, g, steps, 5, a, b);
-        run<2, false, false>(out, in, g, steps, 5, a, b);
-        run<2, false, false>(out, in, g, steps, 2, a, b);
-        run<2, false, false>(out, in, g, steps, 1000, a, b);
+        run<1, false, true, 1>(out, in, g, steps, 1, a, b);
+        run<1, false, true, 2>(out, in, g, steps, 1, a, b);
+        run<2, false, true, 2>(out, in, g, steps, 1, a, b);
+        run<4, false, true, 2>(out, in, g, steps, 1, a, b);
+        run<1, false, true, 4>(out, in, g, steps, 2, a, b);
+        run<2, false, true, 4>(out, in, g, steps, 5, a, b);
     }
     return 0;
 }
