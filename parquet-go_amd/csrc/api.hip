@@ -43,7 +43,9 @@ struct pqd_batch {
     FamilyList fam[16];
     // RLE expand grid
     uint64_t* d_rle_tile_prefix = nullptr;
+    uint32_t* d_rle_tile_item = nullptr; // grid tile -> position in the family list (null: the kernel searches the prefix)
     uint64_t rle_tiles = 0;
+    uint64_t rle_steps = 0;
     // generic tile grids for the element-parallel families
     uint64_t max_src[16] = {0}; // longest src of each family, sizes the tile grids
     std::vector<DevResult> h_results;
@@ -284,10 +286,16 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
             const uint64_t stride = d.dst_stride > 0 ? (uint64_t)d.dst_stride : (uint64_t)d.elem_width;
             uint64_t bound = stride ? d.dst_cap / stride + 1 : 0;
             if (d.num_values >= 0 && (uint64_t)d.num_values < bound) bound = (uint64_t)d.num_values;
-            uint64_t tiles = std::max<uint64_t>(1, (bound + RLE_TILE - 1) / RLE_TILE);
+            const uint64_t steps = std::max<uint64_t>(1, (bound + RLE_TILE - 1) / RLE_TILE);
+            if (steps > 0x7fffffffull) { delete b; return PQD_ERR_INVALID_ARGUMENT; }
+            d.group = d.elem_width == 1 ? 8 : 1; // 1-byte elements: 2 KB per step is too little work for a workgroup
+            d.n_steps = (uint32_t)steps;
+            const uint64_t tiles = (steps + d.group - 1) / d.group;
             rle_prefix.push_back(b->rle_tiles);
             d.tile_base = b->rle_tiles;
+            d.lengths_cap = b->rle_steps; // offset of this page in the tile_run array (pointer set after the carve)
             b->rle_tiles += tiles;
+            b->rle_steps += steps;
         }
     }
     rle_prefix.push_back(b->rle_tiles);
@@ -302,6 +310,9 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
     size_t o_fam[16];
     for (int f = 0; f < 16; f++) o_fam[f] = carve(b->fam[f].items.size() * sizeof(uint32_t));
     const size_t o_rle_prefix = carve(rle_prefix.size() * sizeof(uint64_t));
+    const bool with_tile_item = b->rle_tiles <= (1ull << 24);
+    const size_t o_rle_tile_item = carve(with_tile_item ? b->rle_tiles * sizeof(uint32_t) : 0);
+    const size_t o_rle_tile_run = carve(b->rle_steps * sizeof(uint32_t));
     const size_t o_runs = carve(runs_entries * sizeof(Run));
     const size_t o_lengths = carve(lengths_entries * sizeof(int32_t));
     b->arena_bytes = std::max<size_t>(off, 256);
@@ -310,10 +321,15 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
     b->d_items = reinterpret_cast<DevPage*>(a + o_items);
     b->d_results = reinterpret_cast<DevResult*>(a + o_results);
     b->d_rle_tile_prefix = reinterpret_cast<uint64_t*>(a + o_rle_prefix);
+    b->d_rle_tile_item = with_tile_item ? reinterpret_cast<uint32_t*>(a + o_rle_tile_item) : nullptr;
     Run* runs = reinterpret_cast<Run*>(a + o_runs);
     int32_t* lengths = reinterpret_cast<int32_t*>(a + o_lengths);
     for (DevPage& d : b->items) {
-        if (d.family == FAM_RLE) { d.runs = runs; runs += d.runs_cap; }
+        if (d.family == FAM_RLE) {
+            d.runs = runs; runs += d.runs_cap;
+            d.tile_run = reinterpret_cast<uint32_t*>(a + o_rle_tile_run) + d.lengths_cap;
+            d.lengths_cap = 0;
+        }
         if (d.family == FAM_DBA) {
             // [prefix | suffix], each lengths_cap entries (+4 of slack so that vector stores of the decoder stay inside)
             DevPage& suf = b->items[d.chain];
@@ -338,6 +354,12 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
     }
     ok = ok && hip_ok(hipMemcpy(b->d_rle_tile_prefix, rle_prefix.data(), rle_prefix.size() * sizeof(uint64_t),
                                 hipMemcpyHostToDevice));
+    if (with_tile_item && b->rle_tiles > 0) {
+        std::vector<uint32_t> tile_item(b->rle_tiles);
+        for (size_t k = 0; k + 1 < rle_prefix.size(); k++)
+            std::fill(tile_item.begin() + rle_prefix[k], tile_item.begin() + rle_prefix[k + 1], (uint32_t)k);
+        ok = ok && hip_ok(hipMemcpy(b->d_rle_tile_item, tile_item.data(), tile_item.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     if (!ok) { hipFree(b->arena); delete b; return PQD_ERR_DEVICE; }
     b->h_results.resize(n_items);
     *out = b;
@@ -352,7 +374,7 @@ int pqd_batch_launch(pqd_batch* b, void* hip_stream) {
     launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA64].dev, (uint32_t)b->fam[FAM_DELTA64].items.size(), true, s);
     launch_rle_index(b->d_items, b->d_results, b->fam[FAM_RLE].dev, (uint32_t)b->fam[FAM_RLE].items.size(), s);
     launch_rle_expand(b->d_items, b->d_results, b->fam[FAM_RLE].dev, (uint32_t)b->fam[FAM_RLE].items.size(),
-                      b->d_rle_tile_prefix, b->rle_tiles, s);
+                      b->d_rle_tile_prefix, b->d_rle_tile_item, b->rle_tiles, s);
     auto fam_n = [&](int f) { return (uint32_t)b->fam[f].items.size(); };
     launch_bitpacked(b->d_items, b->d_results, b->fam[FAM_BITPACKED].dev, fam_n(FAM_BITPACKED), b->max_src[FAM_BITPACKED] * 8, s);
     launch_bss(b->d_items, b->d_results, b->fam[FAM_BSS].dev, fam_n(FAM_BSS), b->max_src[FAM_BSS], s);

@@ -183,37 +183,6 @@ struct Walk {
     uint32_t mb_global; // miniblocks started so far
 };
 
-// Cross-lane moves of the wave scan, done with DPP (no LDS round trip).  Lanes
-// whose source lies outside the row, or whose row is masked off, read 0.
-template <int CTRL, int ROW_MASK>
-__device__ inline uint32_t dpp0(uint32_t v) {
-    // all rows enabled: bound_ctrl makes out-of-row sources read 0, no `old` value to set up;
-    // masked rows keep `old`, which then has to be 0
-    if (ROW_MASK == 0xf) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, true);
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
-}
-
-template <int CTRL, int ROW_MASK>
-__device__ inline uint64_t dpp0(uint64_t v) {
-    uint32_t lo = dpp0<CTRL, ROW_MASK>((uint32_t)v);
-    uint32_t hi = dpp0<CTRL, ROW_MASK>((uint32_t)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
-}
-
-// Inclusive prefix sum over the 64 lanes of a wave: Kogge-Stone inside each row
-// of 16 lanes (row_shr 1,2,4,8), then the row totals are passed on with
-// row_bcast:15 (rows 1 and 3) and row_bcast:31 (rows 2 and 3).
-template <typename U>
-__device__ inline U wave_inclusive_scan(U x) {
-    x += dpp0<0x111, 0xf>(x);
-    x += dpp0<0x112, 0xf>(x);
-    x += dpp0<0x114, 0xf>(x);
-    x += dpp0<0x118, 0xf>(x);
-    x += dpp0<0x142, 0xa>(x);
-    x += dpp0<0x143, 0xc>(x);
-    return x;
-}
-
 // Unpacks and prefix-sums one tile: thread t owns deltas 4t..4t+3 of the tile,
 // which sit in the miniblock `s` describes, starting at field `within`; r[]
 // receives its four decoded values.  Adds the tile's sum to `carry`.  Contains

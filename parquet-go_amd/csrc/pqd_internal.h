@@ -50,6 +50,9 @@ struct DevPage {
     int32_t* lengths2;  // DELTA_BYTE_ARRAY suffix lengths
     uint64_t lengths_cap; // entries each
     uint64_t tile_base;   // first tile of this page in its family's tile grid
+    uint32_t* tile_run;   // RLE: per step of RLE_TILE values, the run-table entry holding its first value
+    uint32_t n_steps;     // RLE: steps of RLE_TILE values this page may produce (bound known on the host)
+    uint32_t group;       // RLE: steps one expand workgroup takes (several for 1-byte elements)
     int32_t elem_width;   // output element width in bytes
     int32_t family;       // kernel family
     int32_t chain;        // index of the item whose `consumed` gives this item's src offset, or -1
@@ -95,6 +98,37 @@ typedef uint64_t u64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
 
+// Cross-lane moves of the wave scan, done with DPP (no LDS round trip).  Lanes
+// whose source lies outside the row, or whose row is masked off, read 0.
+template <int CTRL, int ROW_MASK>
+__device__ inline uint32_t dpp0(uint32_t v) {
+    // all rows enabled: bound_ctrl makes out-of-row sources read 0, no `old` value to set up;
+    // masked rows keep `old`, which then has to be 0
+    if (ROW_MASK == 0xf) return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, true);
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false);
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ inline uint64_t dpp0(uint64_t v) {
+    uint32_t lo = dpp0<CTRL, ROW_MASK>((uint32_t)v);
+    uint32_t hi = dpp0<CTRL, ROW_MASK>((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// Inclusive prefix sum over the 64 lanes of a wave: Kogge-Stone inside each row
+// of 16 lanes (row_shr 1,2,4,8), then the row totals are passed on with
+// row_bcast:15 (rows 1 and 3) and row_bcast:31 (rows 2 and 3).
+template <typename U>
+__device__ inline U wave_inclusive_scan(U x) {
+    x += dpp0<0x111, 0xf>(x);
+    x += dpp0<0x112, 0xf>(x);
+    x += dpp0<0x114, 0xf>(x);
+    x += dpp0<0x118, 0xf>(x);
+    x += dpp0<0x142, 0xa>(x);
+    x += dpp0<0x143, 0xc>(x);
+    return x;
+}
+
 // Failure bookkeeping: the first failing condition in stream order wins; a
 // kernel records one with this helper from a single thread.
 __device__ inline void set_status(DevResult* r, int32_t status, int64_t arg) {
@@ -108,7 +142,7 @@ void launch_delta(const DevPage* pages, DevResult* results, const uint32_t* item
 void launch_rle_index(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
                       hipStream_t stream);
 void launch_rle_expand(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
-                       const uint64_t* tile_prefix, uint64_t n_tiles, hipStream_t stream);
+                       const uint64_t* tile_prefix, const uint32_t* tile_item, uint64_t n_tiles, hipStream_t stream);
 
 void launch_bitpacked(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_values,
                       hipStream_t stream);

@@ -76,6 +76,110 @@ __device__ inline int iring_uvarint(const uint8_t* ring8, uint64_t pos, uint64_t
     }
 }
 
+// What a run header at ring position p says (rle.go:295-419): the entry it adds to the run
+// table (kind 0 repeated value, 1 bit-packed, 2 none: an empty run), where the next header
+// starts, or the error the reference reports there.  With `registers_only` the header is
+// decoded from 12 bytes held in registers and anything that needs more (a varint longer
+// than four bytes, the last bytes of the page) is left for the caller: `slow` is set.
+struct RunHeader {
+    uint64_t next;    // position of the next header; where the serial decoder would stop on error
+    uint64_t nvals;   // values (bytes for BOOLEAN) the run adds
+    int64_t err_arg;
+    int32_t err;
+    uint32_t kind, in_off, value;
+    bool slow;
+};
+
+__device__ inline RunHeader parse_run(const uint32_t* ring, uint64_t p, uint64_t end, uint64_t mis, uint64_t start, int32_t mode,
+                                      uint32_t bw, bool registers_only) {
+    const uint8_t* ring8 = reinterpret_cast<const uint8_t*>(ring);
+    RunHeader h;
+    h.next = p; h.nvals = 0; h.err_arg = 0; h.err = PQD_OK; h.kind = 2; h.in_off = 0; h.value = 0; h.slow = false;
+    uint64_t q = p, u = 0;
+    int k;
+    uint64_t after = 0; // the bytes that follow the header, when it was read from registers
+    bool have_after = false;
+    if (end - p >= 12) {
+        const uint32_t d = ((uint32_t)p & IRING_MASK) >> 2, sh = ((uint32_t)p & 3) * 8;
+        const uint32_t w0 = ring[d], w1 = ring[(d + 1) & (IRING_BYTES / 4 - 1)], w2 = ring[(d + 2) & (IRING_BYTES / 4 - 1)];
+        const uint32_t a0 = __builtin_amdgcn_alignbit(w1, w0, sh), a1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+        // Go's binary.Uvarint on up to four bytes
+        if (!(a0 & 0x80)) { u = a0 & 0x7f; k = 1; }
+        else if (!(a0 & 0x8000)) { u = (a0 & 0x7f) | ((a0 >> 1) & 0x3f80); k = 2; }
+        else if (!(a0 & 0x800000)) { u = (a0 & 0x7f) | ((a0 >> 1) & 0x3f80) | ((a0 >> 2) & 0x1fc000); k = 3; }
+        else if (!(a0 & 0x80000000u)) { u = (a0 & 0x7f) | ((a0 >> 1) & 0x3f80) | ((a0 >> 2) & 0x1fc000) | ((a0 >> 3) & 0xfe00000); k = 4; }
+        else if (registers_only) { h.slow = true; return h; }
+        else k = iring_uvarint(ring8, q, end, &u);
+        if (k >= 1 && k <= 4) { after = (((uint64_t)a1 << 32) | a0) >> (8 * k); have_after = true; }
+    } else if (registers_only) {
+        h.slow = true;
+        return h;
+    } else {
+        k = iring_uvarint(ring8, q, end, &u);
+    }
+    if (k == 0) { h.err = PQD_ERR_UNEXPECTED_EOF; h.err_arg = PQD_EOF_RUN_HEADER; return h; }
+    if (k < 0) { h.err = PQD_ERR_VARINT_OVERFLOW; h.err_arg = (int64_t)(p - mis - start); return h; }
+    q += k;
+    const uint64_t count = u >> 1;
+    const bool bitpacked = (u & 1) != 0;
+    if (count == 0) { // empty runs carry no value byte (rle.go:311-313)
+    } else if (count > 0x7fffffffull) { h.err = PQD_ERR_RUN_TOO_LARGE; h.err_arg = (int64_t)count; }
+    else if (bitpacked) {
+        uint64_t nbytes;
+        if (mode == MODE_BOOL) { nbytes = count; h.nvals = count; }      // header counts bytes
+        else { nbytes = count * bw; h.nvals = count * 8; }
+        if (nbytes > end - q) { h.err = PQD_ERR_UNEXPECTED_EOF; h.err_arg = PQD_EOF_BITPACKED_RUN; h.nvals = 0; }
+        else { h.kind = 1; h.in_off = (uint32_t)(q - mis); q += nbytes; }
+    } else if (mode == MODE_BOOL) {
+        if (q < end) { h.value = have_after ? (uint32_t)after & 0xff : ring8[q & IRING_MASK]; q++; }
+        h.nvals = (count + 7) / 8; // bytes of output
+        h.kind = 0;
+    } else {
+        const uint32_t vb = mode == MODE_LEVELS ? (bw != 0 ? 1u : 0u) : (bw + 7) / 8;
+        if (vb > end - q) { h.err = PQD_ERR_UNEXPECTED_EOF; h.err_arg = PQD_EOF_RLE_VALUE; }
+        else {
+            if (have_after) h.value = vb == 0 ? 0u : (uint32_t)after & (vb >= 4 ? 0xffffffffu : ((1u << (8 * vb)) - 1));
+            else for (uint32_t b = 0; b < vb; b++) h.value |= (uint32_t)ring8[(q + b) & IRING_MASK] << (8 * b);
+            q += vb;
+            h.nvals = count;
+            h.kind = 0;
+        }
+    }
+    h.next = q;
+    return h;
+}
+
+// Value of a register in the lane a wave-uniform index names (v_readlane: no LDS round trip).
+__device__ inline uint32_t lane_u32(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+__device__ inline uint64_t lane_u64(uint64_t v, uint32_t lane) {
+    return ((uint64_t)lane_u32((uint32_t)(v >> 32), lane) << 32) | lane_u32((uint32_t)v, lane);
+}
+
+// Records, for every step of RLE_TILE values whose first value lies in the run that starts at
+// value `o` and holds `v` values, that run's table index.  Short spans are written by the lane
+// that owns the run, long ones by the whole wave.
+__device__ inline void publish_steps(gptr<uint32_t> tile_run, uint32_t n_steps, bool has, uint64_t o, uint64_t v, uint32_t idx,
+                                     uint32_t lane) {
+    uint64_t tf = 0, cnt = 0;
+    if (has && v > 0) {
+        tf = (o + RLE_TILE - 1) / RLE_TILE;
+        const uint64_t tl = (o + v - 1) / RLE_TILE;
+        cnt = tl >= tf ? tl - tf + 1 : 0;
+        if (tf >= n_steps) cnt = 0;
+        else if (tf + cnt > n_steps) cnt = n_steps - tf;
+    }
+    if (cnt > 0 && cnt <= 4)
+        for (uint64_t t = 0; t < cnt; t++) tile_run[tf + t] = idx;
+    unsigned long long big = __ballot(cnt > 4);
+    while (big) {
+        const uint32_t l = (uint32_t)__builtin_ctzll(big);
+        big &= big - 1;
+        const uint64_t f = lane_u64(tf, l), c = lane_u64(cnt, l);
+        const uint32_t i = lane_u32(idx, l);
+        for (uint64_t t = lane; t < c; t += 64) tile_run[f + t] = i;
+    }
+}
+
 __global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
                                                       const uint32_t* __restrict__ items) {
     __shared__ uint32_t ring[IRING_BYTES / 4];
@@ -130,6 +234,8 @@ __global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict
 
     uint64_t c_next = 0;
     gptr<Run> runs = as_global(pg.runs);
+    gptr<uint32_t> tile_run = as_global(pg.tile_run);
+    const uint32_t n_steps = pg.n_steps;
     while (!ctl.done) {
         // fill the ring so that [pos, pos + ILOOK) is resident
         const uint64_t pos0 = ctl.pos;
@@ -143,59 +249,96 @@ __global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict
             c_next++;
         }
         __syncthreads();
-        if (tid == 0) {
+        {
+            // Every lane parses the run header that WOULD start at its byte of a 64-byte
+            // window; the headers that really follow one another from `pos` are then picked
+            // out by a scalar walk over the lanes' "next position" (v_readlane hops), and
+            // the lanes on that chain write their run-table entries together.
             uint64_t pos = pos0;
             const uint64_t covered = (c_lo + ILOOK / ICHUNK + 1) * ICHUNK;
             uint64_t n_runs = ctl.n_runs, total = ctl.total;
             int32_t status = PQD_OK;
             int64_t arg = 0;
-            while (pos < end) {
-                if (pos + 16 > covered && covered < end) break; // header might straddle the resident window
-                uint64_t u;
-                int k = iring_uvarint(ring8, pos, end, &u);
-                if (k == 0) { status = PQD_ERR_UNEXPECTED_EOF; arg = PQD_EOF_RUN_HEADER; break; }
-                if (k < 0) { status = PQD_ERR_VARINT_OVERFLOW; arg = (int64_t)(pos - mis - start); break; }
-                pos += k;
-                uint64_t count = u >> 1;
-                const bool bitpacked = (u & 1) != 0;
-                if (count == 0) continue; // empty runs carry no value byte (rle.go:311-313)
-                if (count > 0x7fffffffull) { status = PQD_ERR_RUN_TOO_LARGE; arg = (int64_t)count; break; }
-                Run r;
-                r.out_start = (uint32_t)total;
-                r.in_off = 0;
-                r.value = 0;
-                uint64_t nvals;
-                if (bitpacked) {
-                    uint64_t nbytes;
-                    if (mode == MODE_BOOL) { nbytes = count; nvals = count; }      // header counts bytes
-                    else { nbytes = count * bw; nvals = count * 8; }
-                    if (nbytes > end - pos) { status = PQD_ERR_UNEXPECTED_EOF; arg = PQD_EOF_BITPACKED_RUN; break; }
-                    r.in_off = (uint32_t)(pos - mis);
-                    pos += nbytes;
-                } else if (mode == MODE_BOOL) {
-                    uint32_t word = 0;
-                    if (pos < end) word = ring8[pos++ & IRING_MASK];
-                    r.value = word;
-                    nvals = (count + 7) / 8; // bytes of output
-                } else {
-                    uint32_t vb = mode == MODE_LEVELS ? (bw != 0 ? 1u : 0u) : (bw + 7) / 8;
-                    if (vb > end - pos) { status = PQD_ERR_UNEXPECTED_EOF; arg = PQD_EOF_RLE_VALUE; break; }
-                    uint32_t value = 0;
-                    for (uint32_t b = 0; b < vb; b++) value |= (uint32_t)ring8[(pos + b) & IRING_MASK] << (8 * b);
-                    pos += vb;
-                    r.value = value;
-                    nvals = count;
+            while (pos < end && status == PQD_OK) {
+                if (pos + 64 + 16 > covered && covered < end) break; // a header might straddle the resident window
+                const uint64_t p = pos + tid;
+                const bool valid = p < end;
+                RunHeader h = parse_run(ring, valid ? p : pos, end, mis, start, mode, bw, true);
+                // ---- scalar walk: which lanes hold the headers the stream really has ----
+                const uint32_t rel = (h.next - pos) >= 64 ? 64u : (uint32_t)(h.next - pos);
+                const unsigned long long okm = __ballot(valid && !h.slow && h.err == PQD_OK);
+                unsigned long long chain = 0;
+                uint32_t cur = 0;
+                while (cur < 64 && ((okm >> cur) & 1)) {
+                    chain |= 1ull << cur;
+                    cur = lane_u32(rel, cur);
                 }
-                if (total + nvals > MAX_TOTAL) { status = PQD_ERR_RUN_TOO_LARGE; arg = (int64_t)(total + nvals); break; }
-                r.count_kind = ((uint32_t)nvals << 1) | (bitpacked ? 1u : 0u);
-                store_run(runs, n_runs++, r);
-                total += nvals;
+                // cur < 64 here: that lane is past the end of the page, failed to parse, or needs the slow reader
+                const bool on = (chain >> tid) & 1;
+                // running total along the chain; the first entry that would pass MAX_TOTAL fails (rle.go:373-375)
+                const uint64_t x = wave_inclusive_scan<uint64_t>(on ? h.nvals : 0);
+                const unsigned long long overm = __ballot(on && total + x > MAX_TOTAL);
+                uint32_t stop_lane = 64; // lane whose header ends the decode with an error
+                if (overm) { // cut the chain before the entry that overflows
+                    stop_lane = (uint32_t)__builtin_ctzll(overm);
+                    status = PQD_ERR_RUN_TOO_LARGE;
+                    arg = (int64_t)(total + lane_u64(x, stop_lane));
+                    chain &= (1ull << stop_lane) - 1;
+                } else if (cur < 64 && lane_u32((uint32_t)(valid && !h.slow), cur)) { // the stream continues with a header that does not parse
+                    stop_lane = cur;
+                    status = (int32_t)lane_u32((uint32_t)h.err, cur);
+                    arg = (int64_t)lane_u64((uint64_t)h.err_arg, cur);
+                }
+                const bool keep = ((chain >> tid) & 1) != 0;
+                const unsigned long long recm = __ballot(keep && h.kind != 2);
+                if (keep && h.kind != 2) {
+                    Run r;
+                    r.out_start = (uint32_t)(total + x - h.nvals);
+                    r.in_off = h.in_off;
+                    r.value = h.value;
+                    r.count_kind = ((uint32_t)h.nvals << 1) | (h.kind == 1 ? 1u : 0u);
+                    store_run(runs, n_runs + __popcll(recm & ((1ull << tid) - 1)), r);
+                }
+                publish_steps(tile_run, n_steps, keep && h.kind != 2, total + x - h.nvals, h.nvals,
+                              (uint32_t)(n_runs + __popcll(recm & ((1ull << tid) - 1))), tid);
+                n_runs += __popcll(recm);
+                if (chain) {
+                    const uint32_t l = 63 - (uint32_t)__builtin_clzll(chain);
+                    total += lane_u64(x, l);
+                    pos = lane_u64(h.next, l);
+                }
+                // a failing header leaves the position where the serial decoder would stop reading
+                if (stop_lane < 64) pos = lane_u64(h.next, stop_lane);
+                if (status != PQD_OK) break;
+                // The chain stopped at a header the register reader left alone: every lane reads
+                // that one header the slow way (same result in all lanes), lane 0 records it.
+                if (cur < 64 && pos < end && lane_u32((uint32_t)(valid && h.slow), cur)) {
+                    const RunHeader g = parse_run(ring, pos, end, mis, start, mode, bw, false);
+                    if (g.err != PQD_OK) { status = g.err; arg = g.err_arg; pos = g.next; break; }
+                    if (total + g.nvals > MAX_TOTAL) { status = PQD_ERR_RUN_TOO_LARGE; arg = (int64_t)(total + g.nvals); pos = g.next; break; }
+                    if (g.kind != 2) {
+                        if (tid == 0) {
+                            Run r;
+                            r.out_start = (uint32_t)total;
+                            r.in_off = g.in_off;
+                            r.value = g.value;
+                            r.count_kind = ((uint32_t)g.nvals << 1) | (g.kind == 1 ? 1u : 0u);
+                            store_run(runs, n_runs, r);
+                        }
+                        publish_steps(tile_run, n_steps, tid == 0, total, g.nvals, (uint32_t)n_runs, tid);
+                        n_runs++;
+                    }
+                    total += g.nvals;
+                    pos = g.next;
+                }
             }
-            ctl.pos = pos;
-            ctl.n_runs = n_runs;
-            ctl.total = total;
-            if (status != PQD_OK) { ctl.status = status; ctl.arg = arg; ctl.done = 1; }
-            else if (pos >= end) ctl.done = 1;
+            if (tid == 0) {
+                ctl.pos = pos;
+                ctl.n_runs = n_runs;
+                ctl.total = total;
+                if (status != PQD_OK) { ctl.status = status; ctl.arg = arg; ctl.done = 1; }
+                else if (pos >= end) ctl.done = 1;
+            }
         }
         __syncthreads();
     }
@@ -217,10 +360,15 @@ __global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict
 constexpr int ET = 256;
 constexpr uint32_t STAGE_BYTES = RLE_TILE * 4 + 64; // packed bytes of one tile at 32 bits per value, plus slack
 constexpr uint32_t MAX_TILE_RUNS = RLE_TILE + 2;
+constexpr uint32_t RUN_LOOP_MAX = 16;          // tiles with at most this many runs are expanded run by run
+
+constexpr uint32_t MAX_GROUP = 8;             // steps one expand workgroup may take
 
 struct EShared {
     uint32_t stage[STAGE_BYTES / 4];
     uint32_t run_start[MAX_TILE_RUNS];
+    u32x4 first_run[MAX_GROUP];   // per step: the run that holds its first value ...
+    uint32_t first_idx[MAX_GROUP]; // ... and that run's index
 };
 
 // Number of values the item writes, after the caller's length fix-up
@@ -259,10 +407,30 @@ __device__ inline void store_value(const DevPage& pg, DevResult* res, uint64_t p
     }
 }
 
+// Writes `value` to the values [s0, s1) of a dense, non-dictionary destination: 16 bytes per lane
+// and step once the address is aligned, single elements at the ragged ends.
+template <int ELEM>
+__device__ inline void fill_dense(const DevPage& pg, uint64_t s0, uint64_t s1, uint32_t value) {
+    gptr<uint8_t> base = as_global(pg.dst);
+    const uint64_t b0 = s0 * ELEM, b1 = s1 * ELEM;
+    uint64_t a0 = (((uintptr_t)(pg.dst + b0) + 15) & ~(uintptr_t)15) - (uintptr_t)pg.dst; // first 16-byte boundary at or after b0
+    if (a0 > b1) a0 = b1;
+    const uint64_t a1 = a0 + ((b1 - a0) & ~(uint64_t)15);
+    const uint32_t w = ELEM == 1 ? (value & 0xff) * 0x01010101u : value;
+    u32x4 v = {w, w, w, w};
+    for (uint64_t c = a0 + (uint64_t)threadIdx.x * 16; c < a1; c += (uint64_t)ET * 16) *(gptr<u32x4>)(base + c) = v;
+    for (uint64_t c = b0 + (uint64_t)threadIdx.x * ELEM; c < a0; c += (uint64_t)ET * ELEM) {
+        if (ELEM == 1) base[c] = (uint8_t)value; else *(gptr<uint32_t>)(base + c) = value;
+    }
+    for (uint64_t c = a1 + (uint64_t)threadIdx.x * ELEM; c < b1; c += (uint64_t)ET * ELEM) {
+        if (ELEM == 1) base[c] = (uint8_t)value; else *(gptr<uint32_t>)(base + c) = value;
+    }
+}
+
 // Decodes the tile [t0, t0 + n) of one item.
 template <int ELEM, bool FUSED>
 __device__ inline void expand_tile(EShared& sh, const DevPage& pg, DevResult* res, uint64_t t0, uint32_t n,
-                                   uint64_t total, uint64_t n_runs, uint32_t bw) {
+                                   uint64_t total, uint64_t n_runs, uint32_t bw, uint64_t r0, Run first) {
     const uint32_t tid = threadIdx.x;
     gptr<const Run> runs = as_global((const Run*)pg.runs);
     const uint32_t stride = pg.dst_stride > 0 ? (uint32_t)pg.dst_stride : (uint32_t)ELEM;
@@ -274,18 +442,7 @@ __device__ inline void expand_tile(EShared& sh, const DevPage& pg, DevResult* re
     if (t0 >= total) n_stream = 0;
     else if (t0 + n > total) n_stream = (uint32_t)(total - t0);
 
-    // ---- locate the run holding t0 (uniform binary search) ----
-    uint64_t r0 = 0;
-    if (n_stream > 0) {
-        uint64_t lo = 0, hi = n_runs; // last run with out_start <= t0
-        while (hi - lo > 1) {
-            uint64_t mid = (lo + hi) >> 1;
-            if ((uint64_t)runs[mid].out_start <= t0) lo = mid; else hi = mid;
-        }
-        r0 = lo;
-    }
-    Run first = {0, 0, 0, 0};
-    if (n_stream > 0) first = load_run(runs, r0);
+    // r0 / first: the run holding t0, looked up by the caller (the index kernel left a hint per step)
     const uint64_t first_end = (uint64_t)first.out_start + (first.count_kind >> 1);
     const bool single = n_stream > 0 && first_end >= t0 + n_stream;
 
@@ -294,12 +451,13 @@ __device__ inline void expand_tile(EShared& sh, const DevPage& pg, DevResult* re
     constexpr int G = ELEM == 1 ? 8 : (ELEM == 8 ? 2 : 4);
     constexpr int R = 8 / G;
 
-    if (single && (first.count_kind & 1)) {
-        // ---- fast path: the whole tile lies inside one bit-packed run ----
-        const uint64_t k0 = t0 - first.out_start;            // first field of the tile within the run
+    // ---- values [s0, s0 + sn) of the page, all inside the bit-packed run `run`: packed bytes staged
+    // through LDS with aligned 16-byte loads, every lane cuts its fields out of two LDS dwords ----
+    auto bitpacked_span = [&](const Run& run, uint64_t s0, uint32_t sn) {
+        const uint64_t k0 = s0 - run.out_start;            // first field of the span within the run
         const uint64_t bit0 = k0 * bw;
-        const uint64_t byte0 = (uint64_t)first.in_off + (bit0 >> 3);
-        const uint64_t byte1 = (uint64_t)first.in_off + ((bit0 + (uint64_t)n_stream * bw + 7) >> 3);
+        const uint64_t byte0 = (uint64_t)run.in_off + (bit0 >> 3);
+        const uint64_t byte1 = (uint64_t)run.in_off + ((bit0 + (uint64_t)sn * bw + 7) >> 3);
         const uint64_t mis = (uintptr_t)(src + byte0) & 15;
         gptr<const uint8_t> abase = src + byte0 - mis;
         const uint64_t span = mis + (byte1 - byte0);        // bytes to stage, from the aligned base
@@ -321,8 +479,8 @@ __device__ inline void expand_tile(EShared& sh, const DevPage& pg, DevResult* re
                 uint64_t w01 = (uint64_t)sh.stage[k] | ((uint64_t)sh.stage[k + 1] << 32);
                 v[g] = (uint32_t)(w01 >> s) & mask;
             }
-            if (!FUSED && dense && j + G <= n_stream) {
-                gptr<uint8_t> p = as_global(pg.dst) + (t0 + j) * ELEM;
+            if (!FUSED && dense && j + G <= sn) {
+                gptr<uint8_t> p = as_global(pg.dst) + (s0 + j) * ELEM;
                 if (ELEM == 1) {
                     u32x2_a4 w;
                     w.x = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
@@ -334,46 +492,78 @@ __device__ inline void expand_tile(EShared& sh, const DevPage& pg, DevResult* re
                     w.x = v[0]; w.y = v[1 % G]; w.z = v[2 % G]; w.w = v[3 % G];
                     *(gptr<u32x4_a4>)(p) = w;
                 }
-            } else if (FUSED && dense && ELEM == 8 && j + G <= n_stream) {
+            } else if (FUSED && dense && ELEM == 8 && j + G <= sn) {
                 // gather two 8-byte values, store 16 contiguous bytes
                 uint64_t x[2];
 #pragma unroll
                 for (int g = 0; g < 2; g++) {
                     const uint32_t idx = v[g % G];
                     const bool ok = (uint64_t)idx < pg.dict_len;
-                    if (!ok) atomicMin(reinterpret_cast<unsigned long long*>(&res->aux), (unsigned long long)(t0 + j + g));
+                    if (!ok) atomicMin(reinterpret_cast<unsigned long long*>(&res->aux), (unsigned long long)(s0 + j + g));
                     x[g] = ok ? ((gptr<const uint64_t>)(pg.dict))[idx] : 0ull;
                 }
                 u64x2_a8 w;
                 w.x = x[0]; w.y = x[1];
-                *(gptr<u64x2_a8>)(as_global(pg.dst) + (t0 + j) * 8) = w;
-            } else if (FUSED && dense && ELEM == 4 && j + G <= n_stream) {
+                *(gptr<u64x2_a8>)(as_global(pg.dst) + (s0 + j) * 8) = w;
+            } else if (FUSED && dense && ELEM == 4 && j + G <= sn) {
                 uint32_t x[4];
 #pragma unroll
                 for (int g = 0; g < 4; g++) {
                     const uint32_t idx = v[g % G];
                     const bool ok = (uint64_t)idx < pg.dict_len;
-                    if (!ok) atomicMin(reinterpret_cast<unsigned long long*>(&res->aux), (unsigned long long)(t0 + j + g));
+                    if (!ok) atomicMin(reinterpret_cast<unsigned long long*>(&res->aux), (unsigned long long)(s0 + j + g));
                     x[g] = ok ? ((gptr<const uint32_t>)(pg.dict))[idx] : 0u;
                 }
                 u32x4_a4 w;
                 w.x = x[0]; w.y = x[1]; w.z = x[2]; w.w = x[3];
-                *(gptr<u32x4_a4>)(as_global(pg.dst) + (t0 + j) * 4) = w;
+                *(gptr<u32x4_a4>)(as_global(pg.dst) + (s0 + j) * 4) = w;
             } else {
 #pragma unroll
                 for (int g = 0; g < G; g++)
-                    if (j + g < n_stream) store_value<ELEM, FUSED>(pg, res, t0 + j + g, v[g], stride);
+                    if (j + g < sn) store_value<ELEM, FUSED>(pg, res, s0 + j + g, v[g], stride);
             }
         }
+    };
+
+    if (single && (first.count_kind & 1)) {
+        bitpacked_span(first, t0, n_stream);
     } else if (single) {
         // ---- the whole tile lies inside one repeated run ----
-        for (uint32_t j = tid; j < n_stream; j += ET) store_value<ELEM, FUSED>(pg, res, t0 + j, first.value, stride);
+        if (!FUSED && dense && (ELEM == 1 || ELEM == 4)) fill_dense<(ELEM == 1 ? 1 : 4)>(pg, t0, t0 + n_stream, first.value);
+        else for (uint32_t j = tid; j < n_stream; j += ET) store_value<ELEM, FUSED>(pg, res, t0 + j, first.value, stride);
     } else if (n_stream > 0) {
         // ---- mixed tile: stage the out_start of every run that intersects it ----
         uint64_t avail = n_runs - r0;
         uint32_t nr = avail < MAX_TILE_RUNS ? (uint32_t)avail : MAX_TILE_RUNS;
         for (uint32_t k = tid; k < nr; k += ET) sh.run_start[k] = runs[r0 + k].out_start;
         __syncthreads();
+        // runs that start inside the tile (the first one starts at or before t0)
+        uint32_t in_tile;
+        {
+            uint32_t lo = 0, hi = nr; // last staged run with out_start < t0 + n_stream
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((uint64_t)sh.run_start[mid] < t0 + n_stream) lo = mid; else hi = mid;
+            }
+            in_tile = lo + 1;
+        }
+        if (in_tile <= RUN_LOOP_MAX) {
+            // ---- a few runs: take them one after the other, each with the whole workgroup ----
+            for (uint32_t k = 0; k < in_tile; k++) {
+                const Run rr = load_run(runs, r0 + k);
+                const uint64_t rb = rr.out_start, re = rb + (rr.count_kind >> 1);
+                const uint64_t s0 = rb > t0 ? rb : t0;
+                const uint64_t s1 = re < t0 + n_stream ? re : t0 + n_stream;
+                if (s1 <= s0) continue;
+                if (rr.count_kind & 1) {
+                    __syncthreads(); // the staging buffer is reused from span to span
+                    bitpacked_span(rr, s0, (uint32_t)(s1 - s0));
+                } else {
+                    if (!FUSED && dense && (ELEM == 1 || ELEM == 4)) fill_dense<(ELEM == 1 ? 1 : 4)>(pg, s0, s1, rr.value);
+                    else for (uint64_t q = s0 + tid; q < s1; q += ET) store_value<ELEM, FUSED>(pg, res, q, rr.value, stride);
+                }
+            }
+        } else
         for (uint32_t j = tid; j < n_stream; j += ET) {
             const uint64_t pos = t0 + j;
             uint32_t lo = 0, hi = nr; // last staged run with out_start <= pos
@@ -406,14 +596,19 @@ __device__ inline void expand_tile(EShared& sh, const DevPage& pg, DevResult* re
 
 __global__ __launch_bounds__(ET) void rle_expand_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
                                                        const uint32_t* __restrict__ items, uint32_t n_items,
-                                                       const uint64_t* __restrict__ tile_prefix) {
+                                                       const uint64_t* __restrict__ tile_prefix,
+                                                       const uint32_t* __restrict__ tile_item) {
     __shared__ EShared sh;
-    // which item does this tile belong to: last i with tile_prefix[i] <= blockIdx.x
-    uint32_t lo = 0, hi = n_items;
     const uint64_t b = blockIdx.x;
-    while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (tile_prefix[mid] <= b) lo = mid; else hi = mid;
+    uint32_t lo = 0;
+    if (tile_item != nullptr) {
+        lo = tile_item[b];
+    } else { // which item does this tile belong to: last i with tile_prefix[i] <= blockIdx.x
+        uint32_t hi = n_items;
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (tile_prefix[mid] <= b) lo = mid; else hi = mid;
+        }
     }
     const uint32_t item = items[lo];
     const uint64_t tile = b - tile_prefix[lo];
@@ -425,6 +620,7 @@ __global__ __launch_bounds__(ET) void rle_expand_kernel(const DevPage* __restric
     const bool fused = pg.fused != 0;
     const uint32_t elem = (uint32_t)pg.elem_width;
     const uint32_t stride = pg.dst_stride > 0 ? (uint32_t)pg.dst_stride : elem;
+    const uint32_t group = pg.group;
     uint64_t n_out = output_count(pg, total, fused);
     const uint64_t fit = pg.dst_cap / stride + ((pg.dst_cap % stride) >= elem ? 1 : 0);
     const uint64_t need_bytes = n_out == 0 ? 0 : (n_out - 1) * stride + elem;
@@ -435,19 +631,39 @@ __global__ __launch_bounds__(ET) void rle_expand_kernel(const DevPage* __restric
         res->out_bytes = n_out == 0 ? 0 : (n_out - 1) * (uint64_t)stride + elem;
         if (too_small && res->status == PQD_OK) { res->status = PQD_ERR_DST_TOO_SMALL; res->arg = (int64_t)need_bytes; }
     }
-    const uint64_t t0 = tile * RLE_TILE;
-    if (t0 >= n_out) return;
-    const uint32_t n = n_out - t0 < RLE_TILE ? (uint32_t)(n_out - t0) : RLE_TILE;
-    if (fused) {
-        switch (elem) {
-            case 4: expand_tile<4, true>(sh, pg, res, t0, n, total, n_runs, bw); break;
-            case 8: expand_tile<8, true>(sh, pg, res, t0, n, total, n_runs, bw); break;
-            default: expand_tile<12, true>(sh, pg, res, t0, n, total, n_runs, bw); break;
+    // the first run of every step, fetched together: one round trip instead of two per step
+    if (threadIdx.x < group) {
+        const uint64_t ts = (tile * group + threadIdx.x) * RLE_TILE;
+        uint32_t idx = 0;
+        u32x4 w = (u32x4)(0u);
+        if (ts < n_out && ts < total) {
+            if (n_runs > 1) idx = as_global((const uint32_t*)pg.tile_run)[ts / RLE_TILE]; // a single run needs no hint
+            w = *(gptr<const u32x4>)(as_global((const Run*)pg.runs) + idx);
         }
-    } else if (elem == 1) {
-        expand_tile<1, false>(sh, pg, res, t0, n, total, n_runs, bw);
-    } else {
-        expand_tile<4, false>(sh, pg, res, t0, n, total, n_runs, bw);
+        sh.first_idx[threadIdx.x] = idx;
+        sh.first_run[threadIdx.x] = w;
+    }
+    __syncthreads();
+    for (uint32_t step = 0; step < group; step++) {
+        const uint64_t t0 = (tile * group + step) * RLE_TILE;
+        if (t0 >= n_out) return;
+        const uint64_t r0 = sh.first_idx[step];
+        const u32x4 fw = sh.first_run[step];
+        Run first;
+        first.out_start = fw.x; first.in_off = fw.y; first.value = fw.z; first.count_kind = fw.w;
+        const uint32_t n = n_out - t0 < RLE_TILE ? (uint32_t)(n_out - t0) : RLE_TILE;
+        if (fused) {
+            switch (elem) {
+                case 4: expand_tile<4, true>(sh, pg, res, t0, n, total, n_runs, bw, r0, first); break;
+                case 8: expand_tile<8, true>(sh, pg, res, t0, n, total, n_runs, bw, r0, first); break;
+                default: expand_tile<12, true>(sh, pg, res, t0, n, total, n_runs, bw, r0, first); break;
+            }
+        } else if (elem == 1) {
+            expand_tile<1, false>(sh, pg, res, t0, n, total, n_runs, bw, r0, first);
+        } else {
+            expand_tile<4, false>(sh, pg, res, t0, n, total, n_runs, bw, r0, first);
+        }
+        if (step + 1 < group) __syncthreads(); // the next step restages the LDS buffers
     }
 }
 
@@ -460,10 +676,10 @@ void launch_rle_index(const DevPage* pages, DevResult* results, const uint32_t* 
 }
 
 void launch_rle_expand(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
-                       const uint64_t* tile_prefix, uint64_t n_tiles, hipStream_t stream) {
+                       const uint64_t* tile_prefix, const uint32_t* tile_item, uint64_t n_tiles, hipStream_t stream) {
     if (n_items == 0 || n_tiles == 0) return;
     hipLaunchKernelGGL(rle_expand_kernel, dim3((uint32_t)n_tiles), dim3(ET), 0, stream, pages, results, items, n_items,
-                       tile_prefix);
+                       tile_prefix, tile_item);
 }
 
 } // namespace pqd
