@@ -360,7 +360,7 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
             std::fill(tile_item.begin() + rle_prefix[k], tile_item.begin() + rle_prefix[k + 1], (uint32_t)k);
         ok = ok && hip_ok(hipMemcpy(b->d_rle_tile_item, tile_item.data(), tile_item.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    if (!ok) { hipFree(b->arena); delete b; return PQD_ERR_DEVICE; }
+    if (!ok) { (void)hipFree(b->arena); delete b; return PQD_ERR_DEVICE; }
     b->h_results.resize(n_items);
     *out = b;
     return PQD_OK;

@@ -660,7 +660,6 @@ __global__ __launch_bounds__(DT) void delta_decode_kernel(const DevPage* __restr
     const DevPage& pg = pages[item];
     DevResult* res = &results[item];
     const uint32_t tid = threadIdx.x;
-    const uint32_t lane = tid & 63, wave = tid >> 6;
     const uint8_t* ring8 = reinterpret_cast<const uint8_t*>(sh.ring);
 
     // A chained item starts where the previous stream of the same page ended.

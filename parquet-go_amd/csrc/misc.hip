@@ -248,81 +248,151 @@ __device__ inline uint32_t le32(const uint8_t* p) {
     return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24);
 }
 
-// plain.go:76-94: a walk over `u32 length | bytes` records.  Lane 0 walks the
-// lengths of up to 64 records out of an LDS copy of the page, then the wave
-// copies their bytes.
+// Four bytes at any LDS byte offset: two aligned dwords and a funnel shift.
+__device__ inline uint32_t lds_u32(const uint32_t* stage32, uint32_t off) {
+    const uint32_t d = off >> 2;
+    return __builtin_amdgcn_alignbit(stage32[d + 1], stage32[d], (off & 3) * 8);
+}
+
+// Copies `len` bytes from LDS offset `pos` to global `dst`, four at a time: what one lane does
+// for its own value while the other lanes do theirs.
+__device__ inline void lane_copy(gptr<uint8_t> dst, const uint32_t* stage32, uint32_t pos, uint32_t len, uint32_t round) {
+    const uint32_t b = round * 4;
+    if (b + 4 <= len) {
+        *(gptr<u32_a1>)(dst + b) = lds_u32(stage32, pos + b);
+    } else if (b < len) {
+        const uint32_t w = lds_u32(stage32, pos + b);
+        for (uint32_t k = 0; b + k < len; k++) dst[b + k] = (uint8_t)(w >> (8 * k));
+    }
+}
+
+// plain.go:76-94: a walk over `u32 length | bytes` records.  Each record's position depends on
+// the one before, so the lengths are found speculatively: lane l guesses that record l starts
+// l * (4 + g) bytes after the first, g being the length of the record before, reads the length
+// it finds there, and the guess holds for every lane whose predecessors all measured g again
+// (equal lengths in a row -- ids, dates, fixed formats -- give 64 records per round, anything else
+// at least one).  Rounds fill a batch of 64 records out of an LDS copy of the page; then every
+// lane owns one record: offsets by a wave scan, bytes copied four at a time by all lanes at once.
 __global__ __launch_bounds__(WT) void plain_byte_array_kernel(const DevPage* __restrict__ pages,
                                                               DevResult* __restrict__ results,
                                                               const uint32_t* __restrict__ items) {
-    __shared__ __attribute__((aligned(16))) uint8_t stage[PSTAGE];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[PSTAGE + 16];
     __shared__ uint32_t v_pos[PBATCH], v_len[PBATCH];
-    __shared__ uint32_t ctl[6];
+    const uint32_t* stage32 = reinterpret_cast<const uint32_t*>(stage);
     const uint32_t item = items[blockIdx.x];
     const DevPage& pg = pages[item];
     DevResult* res = &results[item];
     gptr<const uint8_t> src = as_global(pg.src);
     gptr<uint8_t> dst = as_global(pg.dst);
     gptr<uint32_t> offsets = as_global(pg.offsets);
-    const uint64_t n = pg.src_len;
+    const uint64_t n = pg.src_len, dst_cap = pg.dst_cap, offsets_cap = pg.offsets_cap;
     const uint32_t lane = threadIdx.x;
     uint64_t i = 0, out = 0, nv = 0;
+    uint32_t guess = 0;
     int32_t status = PQD_OK;
     int64_t arg = 0;
     while (i < n && status == PQD_OK) {
         // stage [i, i + PSTAGE)
-        const uint64_t avail = n - i < PSTAGE ? n - i : PSTAGE;
+        const uint32_t avail = n - i < PSTAGE ? (uint32_t)(n - i) : PSTAGE;
         stage_fill(stage, src + i, avail, lane);
         __syncthreads();
-        if (lane == 0) {
-            uint64_t p = 0, o = out, cnt = 0;
-            int32_t st = PQD_OK;
-            int64_t a = 0;
-            uint32_t big = 0; // a record that does not fit the stage: handled on its own
-            while (cnt < PBATCH && i + p < n) {
-                if (n - (i + p) < 4) { st = PQD_ERR_UNEXPECTED_EOF; a = PQD_EOF_PLAIN_BYTE_ARRAY; break; }
-                if (p + 4 > avail) break; // header not staged: next round starts at it
-                const uint64_t len = le32(stage + p);
-                if (len > n - 4 || len > n - (i + p + 4)) { st = PQD_ERR_UNEXPECTED_EOF; a = PQD_EOF_PLAIN_BYTE_ARRAY; break; }
-                if (nv + cnt + 2 > pg.offsets_cap) { st = PQD_ERR_OFFSETS_TOO_SMALL; a = (int64_t)(nv + cnt + 2); break; }
-                if (o + len > pg.dst_cap) { st = PQD_ERR_DST_TOO_SMALL; a = (int64_t)(o + len); break; }
-                if (p + 4 + len > avail) { // bytes not all staged
-                    if (cnt == 0) { v_pos[0] = (uint32_t)(p + 4); v_len[0] = (uint32_t)len; cnt = 1; p += 4 + len; o += len; big = 1; }
-                    break;
-                }
-                v_pos[cnt] = (uint32_t)(p + 4);
-                v_len[cnt] = (uint32_t)len;
-                cnt++;
-                p += 4 + len;
-                o += len;
+        const uint64_t left = n - i; // bytes from the start of the stage to the end of the page
+        uint32_t p = 0, cnt = 0;     // position in the stage, records in the batch
+        bool big = false;            // a record that does not fit the stage: handled on its own
+        while (cnt < PBATCH && p < left && status == PQD_OK) {
+            // ---- one speculative round ----
+            const uint64_t c64 = (uint64_t)p + (uint64_t)lane * (4ull + guess);
+            const bool inwin = c64 + 4 <= avail;                 // header staged
+            const uint32_t c = inwin ? (uint32_t)c64 : 0;
+            const uint32_t len = lds_u32(stage32, c);
+            // 0 fine, 1 truncated input (plain.ErrTooShort), 2 stop here: not (all) staged
+            uint32_t what = 0;
+            if (c64 >= left) what = 2;                           // past the last record
+            else if (left - c64 < 4) what = 1;
+            else if (!inwin) what = 2;
+            else if (len > n - 4 || len > left - c64 - 4) what = 1;
+            else if (c64 + 4 + len > avail) what = 2;
+            const unsigned long long same = __ballot(what == 0 && len == guess);
+            const uint32_t lead = same == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~same);
+            // lanes [0, lead) measured the guess again; lane `lead` sits at a true record start too
+            uint32_t valid = lead;
+            uint32_t stop_what = 2;
+            if (lead < 64) {
+                stop_what = lane_u32(what, lead);
+                if (stop_what == 0) valid = lead + 1;
             }
-            ctl[0] = (uint32_t)cnt; ctl[1] = (uint32_t)st; ctl[2] = (uint32_t)a; ctl[3] = (uint32_t)((uint64_t)a >> 32);
-            ctl[4] = big; ctl[5] = (uint32_t)p;
+            if (valid > PBATCH - cnt) { valid = PBATCH - cnt; stop_what = 0; }
+            if (lane < valid) { v_pos[cnt + lane] = c + 4; v_len[cnt + lane] = len; }
+            if (valid > 0) {
+                const uint32_t l = valid - 1;
+                guess = lane_u32(len, l);
+                p = lane_u32(c, l) + 4 + guess;
+                cnt += valid;
+            }
+            if (valid == 0 || (valid <= lead && lead < 64 && stop_what != 0)) {
+                // the record after the valid ones cannot be taken this round
+                const uint32_t at = valid == 0 ? 0 : lead; // lane holding it (valid == lead here)
+                const uint32_t w = valid == 0 ? lane_u32(what, 0) : stop_what;
+                if (w == 1) { status = PQD_ERR_UNEXPECTED_EOF; arg = PQD_EOF_PLAIN_BYTE_ARRAY; }
+                else if (cnt == 0 && lane_u32((uint32_t)inwin, at) && lane_u32((uint32_t)(c64 < left), at)) {
+                    // its header is staged but its bytes are not, and nothing else is pending: take it alone
+                    if (lane == 0) { v_pos[0] = lane_u32(c, at) + 4; v_len[0] = lane_u32(len, at); }
+                    big = true;
+                    cnt = 1;
+                }
+                break;
+            }
         }
         __syncthreads();
-        const uint32_t cnt = ctl[0];
-        const bool big = ctl[4] != 0;
-        // offsets of the batch, then the bytes
-        uint64_t o = out;
-        for (uint32_t v = 0; v < cnt; v++) {
-            const uint32_t len = v_len[v], pos = v_pos[v];
-            if (lane == 0) offsets[nv + v] = (uint32_t)o;
-            if (big) {
-                for (uint64_t b = lane; b < len; b += WT) dst[o + b] = src[i + pos + b];
-            } else {
-                for (uint32_t b = lane; b < len; b += WT) dst[o + b] = stage[pos + b];
+        if (big) {
+            // one record longer than the stage: straight from global memory, all lanes on it
+            const uint32_t blen = v_len[0], bpos = v_pos[0];
+            if (nv + 2 > offsets_cap) { status = PQD_ERR_OFFSETS_TOO_SMALL; arg = (int64_t)(nv + 2); }
+            else if (out + blen > dst_cap) { status = PQD_ERR_DST_TOO_SMALL; arg = (int64_t)(out + blen); }
+            else {
+                if (lane == 0) offsets[nv] = (uint32_t)out;
+                for (uint64_t b = lane; b < blen; b += WT) dst[out + b] = src[i + bpos + b];
+                out += blen;
+                nv += 1;
+                i += (uint64_t)bpos + blen;
+                guess = blen;
             }
-            o += len;
+        } else {
+            const uint32_t pos = lane < cnt ? v_pos[lane] : 0, len = lane < cnt ? v_len[lane] : 0;
+            const uint32_t incl = wave_inclusive_scan<uint32_t>(len);
+            const uint64_t o = out + (incl - len);
+            // capacity checks in record order (plain.go walks and appends one value at a time)
+            uint32_t cap_err = 0;
+            if (lane < cnt) {
+                if (nv + lane + 2 > offsets_cap) cap_err = 1;
+                else if (o + len > dst_cap) cap_err = 2;
+            }
+            const unsigned long long capm = __ballot(cap_err != 0);
+            uint32_t good = cnt;
+            if (capm) {
+                good = (uint32_t)__builtin_ctzll(capm);
+                const uint32_t e = lane_u32(cap_err, good);
+                status = e == 1 ? PQD_ERR_OFFSETS_TOO_SMALL : PQD_ERR_DST_TOO_SMALL;
+                arg = e == 1 ? (int64_t)(nv + good + 2) : (int64_t)(lane_u64(o, good) + lane_u32(len, good));
+            }
+            const uint32_t mylen = lane < good ? len : 0;
+            if (lane < good) offsets[nv + lane] = (uint32_t)o;
+            // the longest record of the batch sets the number of rounds
+            uint32_t longest = mylen;
+            for (int d = 32; d > 0; d >>= 1) { const uint32_t y = __shfl_xor(longest, d); longest = y > longest ? y : longest; }
+            for (uint32_t r = 0; r * 4 < longest; r++) lane_copy(dst + o, stage32, pos, mylen, r);
+            if (good > 0) {
+                out = lane_u64(o, good - 1) + lane_u32(len, good - 1);
+                nv += good;
+                i += (uint64_t)lane_u32(pos, good - 1) + lane_u32(len, good - 1);
+            }
+            if (cnt == 0 && status == PQD_OK) break; // nothing could be taken and nothing failed: cannot happen, but never spin
         }
-        out = o;
-        nv += cnt;
-        status = (int32_t)ctl[1];
-        arg = (int64_t)(((uint64_t)ctl[3] << 32) | ctl[2]);
-        i += big ? (uint64_t)v_pos[0] + v_len[0] : ctl[5];
         __syncthreads();
     }
     if (lane == 0) {
         if (status == PQD_OK) {
-            if (nv + 1 > pg.offsets_cap) { status = PQD_ERR_OFFSETS_TOO_SMALL; arg = (int64_t)(nv + 1); }
+            if (nv + 1 > offsets_cap) { status = PQD_ERR_OFFSETS_TOO_SMALL; arg = (int64_t)(nv + 1); }
             else offsets[nv] = (uint32_t)out;
         }
         finish(res, status, arg, nv, out, status == PQD_OK ? n : i);
@@ -424,7 +494,7 @@ __global__ __launch_bounds__(MT) void dlba_copy_kernel(const DevPage* __restrict
 // ------------------------------------------------------- DELTA_BYTE_ARRAY --
 
 constexpr uint32_t LAST_CAP = 2048;  // leading bytes of the previous value kept in LDS
-constexpr uint32_t DSTAGE = 8192;    // suffix bytes staged per round
+constexpr uint32_t DSTAGE = 8192;    // suffix bytes staged per pass
 
 __device__ inline uint64_t wave_excl_scan64(uint64_t v, uint32_t lane, uint64_t* total) {
     uint64_t x = v;
@@ -445,7 +515,7 @@ __device__ inline uint64_t wave_excl_scan64(uint64_t v, uint32_t lane, uint64_t*
 // prefix.
 __global__ __launch_bounds__(WT) void dba_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
                                                  const uint32_t* __restrict__ items) {
-    __shared__ __attribute__((aligned(16))) uint8_t stage[DSTAGE];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[DSTAGE + 16];
     __shared__ __attribute__((aligned(16))) uint8_t last[LAST_CAP];
     const uint32_t item = items[blockIdx.x];
     const DevPage& pg = pages[item];
@@ -505,24 +575,52 @@ __global__ __launch_bounds__(WT) void dba_kernel(const DevPage* __restrict__ pag
             status = __shfl(err, first);
             arg = __shfl(err_arg, first);
         }
-        // values [done, done + m) are good; the staged span may cut the round shorter
+        // values [done, done + m) are good; the staged spans may cut the round into several passes
         uint32_t taken = 0;
         while (taken < m) {
-            const uint64_t span0 = __shfl(s_off, taken);
-            // how many values from `taken` on have their suffix bytes inside one stage?
-            const bool fits = lane >= taken && lane < m && (s_off + s_pos - span0) <= DSTAGE;
+            const uint64_t span0 = lane_u64(s_off, taken);
+            // how many values from `taken` on fit one pass: suffix bytes in `stage`, no value longer
+            // than the wave can hold in registers (4 bytes per lane)
+            const bool fits = lane >= taken && lane < m && (s_off + s_pos - span0) <= DSTAGE && p_pos + s_pos <= 4 * WT;
             const unsigned long long fmask = __ballot(fits) >> taken;
-            uint32_t cnt = fmask == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fmask);
-            const bool single_big = cnt == 0; // one value whose suffix alone exceeds the stage
-            if (single_big) cnt = 1;
-            const uint64_t span1 = __shfl(s_off + s_pos, taken + cnt - 1);
-            if (!single_big) {
+            const uint32_t cnt = fmask == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~fmask);
+            if (cnt > 0) {
+                // ---- fast pass.  The running value lives in registers, lane b holding its bytes
+                // 4b..4b+3: a new value keeps the bytes below its prefix length and takes the rest
+                // from the staged suffix bytes, so the only thing carried from value to value is a
+                // register, and the LDS reads of the suffixes do not wait for one another. ----
+                const uint64_t span1 = lane_u64(s_off + s_pos, taken + cnt - 1);
                 stage_fill(stage, data + span0, span1 - span0, lane);
+                __syncthreads();
+                const uint32_t* stage32 = reinterpret_cast<const uint32_t*>(stage);
+                const uint32_t so32 = (uint32_t)(s_off - span0), p32 = (uint32_t)p_pos, s32 = (uint32_t)s_pos;
+                if (with_offsets && lane >= taken && lane < taken + cnt) offsets[done + lane] = (uint32_t)o_off;
+                uint32_t cur = reinterpret_cast<const uint32_t*>(last)[lane];
+                for (uint32_t v = taken; v < taken + cnt; v++) {
+                    const uint32_t p_v = lane_u32(p32, v), s_v = lane_u32(s32, v), so = lane_u32(so32, v);
+                    const uint64_t oo = lane_u64(o_off, v);
+                    const int32_t k = (int32_t)p_v - (int32_t)(4 * lane);   // bytes of this lane's dword below the prefix length
+                    const uint32_t suf = lds_u32(stage32, so + (k < 0 ? (uint32_t)(-k) : 0u));
+                    if (k <= 0) cur = suf;
+                    else if (k < 4) cur = (cur & ((1u << (8 * k)) - 1)) | (suf << (8 * k));
+                    const uint32_t len = p_v + s_v;
+                    gptr<uint8_t> o = dst + oo + 4 * lane;
+                    if (4 * lane + 4 <= len) *(gptr<u32_a1>)(o) = cur;
+                    else if (4 * lane < len) for (uint32_t q = 0; 4 * lane + q < len; q++) o[q] = (uint8_t)(cur >> (8 * q));
+                }
+                const uint32_t last_len = lane_u32(p32 + s32, taken + cnt - 1);
+                reinterpret_cast<uint32_t*>(last)[lane] = cur; // the slow pass and the next fast pass start from here
+                prev_len = last_len;
+                prev_out = lane_u64(o_off, taken + cnt - 1);
+                __syncthreads();
+                taken += cnt;
+                continue;
             }
-            __syncthreads();
-            for (uint32_t v = taken; v < taken + cnt; v++) {
-                const uint64_t p_v = __shfl(p_pos, v), s_v = __shfl(s_pos, v);
-                const uint64_t so = __shfl(s_off, v), oo = __shfl(o_off, v);
+            // ---- slow pass: one value that is long, or follows a long one ----
+            {
+                const uint32_t v = taken;
+                const uint64_t p_v = lane_u64(p_pos, v), s_v = lane_u64(s_pos, v);
+                const uint64_t so = lane_u64(s_off, v), oo = lane_u64(o_off, v);
                 if (with_offsets && lane == 0) offsets[done + v] = (uint32_t)oo;
                 const uint64_t len = p_v + s_v;
                 // prefix bytes: from the LDS copy of the previous value, beyond it from where that value went
@@ -531,11 +629,7 @@ __global__ __launch_bounds__(WT) void dba_kernel(const DevPage* __restrict__ pag
                     for (uint64_t b = LAST_CAP + lane; b < p_v; b += WT) dst[oo + b] = dst[prev_out + b];
                 }
                 // suffix bytes into the LDS copy (as far as it reaches) ...
-                if (!single_big) {
-                    for (uint64_t b = lane; b < s_v && p_v + b < LAST_CAP; b += WT) last[p_v + b] = stage[so - span0 + b];
-                } else {
-                    for (uint64_t b = lane; b < s_v && p_v + b < LAST_CAP; b += WT) last[p_v + b] = data[so + b];
-                }
+                for (uint64_t b = lane; b < s_v && p_v + b < LAST_CAP; b += WT) last[p_v + b] = data[so + b];
                 __syncthreads();
                 // ... the value's first bytes from the LDS copy ...
                 const uint64_t head = len < LAST_CAP ? len : LAST_CAP;
@@ -543,17 +637,13 @@ __global__ __launch_bounds__(WT) void dba_kernel(const DevPage* __restrict__ pag
                 // ... and the suffix bytes that did not pass through it
                 if (len > LAST_CAP) {
                     const uint64_t from = p_v > LAST_CAP ? 0 : LAST_CAP - p_v; // first suffix byte not in `last`
-                    if (!single_big) {
-                        for (uint64_t b = from + lane; b < s_v; b += WT) dst[oo + p_v + b] = stage[so - span0 + b];
-                    } else {
-                        for (uint64_t b = from + lane; b < s_v; b += WT) dst[oo + p_v + b] = data[so + b];
-                    }
+                    for (uint64_t b = from + lane; b < s_v; b += WT) dst[oo + p_v + b] = data[so + b];
                 }
                 prev_len = len;
                 prev_out = oo;
                 __syncthreads();
+                taken += 1;
             }
-            taken += cnt;
         }
         if (m > 0) {
             src_base = __shfl(s_off + s_pos, m - 1);

@@ -129,6 +129,12 @@ __device__ inline U wave_inclusive_scan(U x) {
     return x;
 }
 
+// Value of a register in the lane a wave-uniform index names (v_readlane: no LDS round trip).
+__device__ inline uint32_t lane_u32(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
+__device__ inline uint64_t lane_u64(uint64_t v, uint32_t lane) {
+    return ((uint64_t)lane_u32((uint32_t)(v >> 32), lane) << 32) | lane_u32((uint32_t)v, lane);
+}
+
 // Failure bookkeeping: the first failing condition in stream order wins; a
 // kernel records one with this helper from a single thread.
 __device__ inline void set_status(DevResult* r, int32_t status, int64_t arg) {

@@ -149,12 +149,6 @@ __device__ inline RunHeader parse_run(const uint32_t* ring, uint64_t p, uint64_t
     return h;
 }
 
-// Value of a register in the lane a wave-uniform index names (v_readlane: no LDS round trip).
-__device__ inline uint32_t lane_u32(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
-__device__ inline uint64_t lane_u64(uint64_t v, uint32_t lane) {
-    return ((uint64_t)lane_u32((uint32_t)(v >> 32), lane) << 32) | lane_u32((uint32_t)v, lane);
-}
-
 // Records, for every step of RLE_TILE values whose first value lies in the run that starts at
 // value `o` and holds `v` values, that run's table index.  Short spans are written by the lane
 // that owns the run, long ones by the whole wave.
@@ -188,8 +182,6 @@ __global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict
     const DevPage& pg = pages[item];
     DevResult* res = &results[item];
     const uint32_t tid = threadIdx.x;
-    const uint8_t* ring8 = reinterpret_cast<const uint8_t*>(ring);
-
     gptr<const uint8_t> src = as_global(pg.src);
     uint64_t src_len = pg.src_len;
     int32_t mode = pg.kind == PQD_KIND_LEVELS ? MODE_LEVELS : (pg.kind == PQD_KIND_BOOLEAN ? MODE_BOOL : MODE_INT32);

@@ -164,6 +164,13 @@ def main():
     run("DELTA_LENGTH_BYTE_ARRAY urls (32 Ki)", [dlba_page(v) for v in svals], 64, E.DELTA_LENGTH_BYTE_ARRAY, K.BYTE_ARRAY, 0, nb, 32768, joined)
     run("DELTA_BYTE_ARRAY urls (32 Ki)", [dba_page(v) for v in svals], 64, E.DELTA_BYTE_ARRAY, K.BYTE_ARRAY, 0, nb, 32768, joined, steps=5)
     run("PLAIN byte arrays urls (32 Ki)", [plain_ba_page(v) for v in svals], 64, E.PLAIN, K.BYTE_ARRAY, 0, nb, 32768, joined, steps=5)
+    # the same strings cut into many small pages: the byte-array walkers run one wavefront per page
+    small = [strings(rng, 4096) for _ in range(16)]
+    sj = [np.frombuffer(b"".join(v), np.uint8) for v in small]
+    snb = max(j.size for j in sj)
+    run("DELTA_LENGTH_BYTE_ARRAY urls (4 Ki)", [dlba_page(v) for v in small], 128, E.DELTA_LENGTH_BYTE_ARRAY, K.BYTE_ARRAY, 0, snb, 4096, sj)
+    run("DELTA_BYTE_ARRAY urls (4 Ki)", [dba_page(v) for v in small], 128, E.DELTA_BYTE_ARRAY, K.BYTE_ARRAY, 0, snb, 4096, sj, steps=5)
+    run("PLAIN byte arrays urls (4 Ki)", [plain_ba_page(v) for v in small], 128, E.PLAIN, K.BYTE_ARRAY, 0, snb, 4096, sj, steps=5)
 
 
 if __name__ == "__main__":
