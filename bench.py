@@ -268,12 +268,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    # One rank per GPU over RCCL.  PQD_BENCH_REHEARSE=1 is for a box with fewer GPUs than ranks:
+    # ranks share the GPUs there are and synchronise over gloo (RCCL refuses two ranks on one GPU),
+    # which exercises the N > 1 code path; its numbers mean nothing.
+    rehearse = os.environ.get("PQD_BENCH_REHEARSE") == "1"
+    device = local_rank % torch.cuda.device_count() if (world > 1 and rehearse) else (local_rank if world > 1 else 0)
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if rehearse:
+            dist_mod.init_process_group(backend="gloo")
+        else:
+            dist_mod.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{device}"))
         dist = dist_mod
-    device = local_rank if world > 1 else 0
     torch.cuda.set_device(device)
     ctx = pkg.Context(device)
     stream = torch.cuda.current_stream(device).cuda_stream
@@ -300,7 +307,7 @@ def main():
                     raise RuntimeError(f"page {slot} decoded wrong")
 
     wall, kernel_ms = time_steps(S, torch, wl, stream, args.steps, args.warmup, dist)
-    wall_max = S.max_over_ranks(wall, dist, f"cuda:{device}")
+    wall_max = S.max_over_ranks(wall, dist, "cpu" if rehearse else f"cuda:{device}")
     ms_per_step = wall_max / args.steps * 1e3
     value = S.whole_job_rate(wl.decoded_bytes / 1e9, world, wall_max / args.steps)
     avg_kernel_s = float(np.mean(kernel_ms)) / 1e3
