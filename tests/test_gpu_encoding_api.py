@@ -203,3 +203,38 @@ def test_dictionary_lookup():
         with pytest.raises(IndexError):
             D.Lookup(np.array([-1], np.int32))
         D.close()
+
+
+def test_dictionary_lookup_on_device_pointers():
+    # pqd_dict_lookup_device: the same gather enqueued on a stream, everything resident in HBM
+    import ctypes as C
+    import torch
+    P = pkg()
+    from tests.gpu_util import ctx
+    L = P.lib()
+    rng = np.random.default_rng(23)
+    stream = torch.cuda.current_stream(0).cuda_stream
+    for dt, stride in ((np.int64, 8), (np.int32, 4), (np.int64, 24)):
+        d = rng.integers(-10**9, 10**9, size=3001).astype(dt)
+        idx = rng.integers(0, 3001, size=50000, dtype=np.int32)
+        d_t, i_t = torch.from_numpy(d).cuda(), torch.from_numpy(idx).cuda()
+        rows = torch.full((idx.size * stride,), 0xEE, dtype=torch.uint8, device="cuda")
+        st = torch.zeros(2, dtype=torch.int64, device="cuda")
+        rc = L.pqd_dict_lookup_device(ctx().handle, d_t.data_ptr(), d.size, d.dtype.itemsize, i_t.data_ptr(), idx.size,
+                                      rows.data_ptr(), stride, st.data_ptr(), C.c_void_p(stream))
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert st.tolist() == [0, 0]
+        want = O.dict_lookup(d, idx, stride).values.reshape(-1, stride)
+        got = rows.cpu().numpy().reshape(-1, stride)
+        w = d.dtype.itemsize
+        assert np.array_equal(got[:, :w], want[:, :w]) and (got[:, w:] == 0xEE).all()
+        # an index outside the dictionary: status and the position of the first offender
+        bad = idx.copy()
+        bad[[40000, 777]] = [3001, -5]
+        i_t = torch.from_numpy(bad).cuda()
+        st.zero_()
+        rc = L.pqd_dict_lookup_device(ctx().handle, d_t.data_ptr(), d.size, d.dtype.itemsize, i_t.data_ptr(), bad.size,
+                                      rows.data_ptr(), stride, st.data_ptr(), C.c_void_p(stream))
+        torch.cuda.synchronize()
+        assert rc == 0 and st.tolist() == [P.STATUS.INDEX_OUT_OF_BOUNDS, 777]
