@@ -97,6 +97,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint64_t u64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
 typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint32_t u32x2_a4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 // Cross-lane moves of the wave scan, done with DPP (no LDS round trip).  Lanes
 // whose source lies outside the row, or whose row is masked off, read 0.

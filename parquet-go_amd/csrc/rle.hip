@@ -402,7 +402,8 @@ __device__ inline void store_value(const DevPage& pg, DevResult* res, uint64_t p
 // Writes `value` to the values [s0, s1) of a dense, non-dictionary destination: 16 bytes per lane
 // and step once the address is aligned, single elements at the ragged ends.
 template <int ELEM>
-__device__ inline void fill_dense(const DevPage& pg, uint64_t s0, uint64_t s1, uint32_t value) {
+__device__ inline void fill_dense(const DevPage& pg, uint64_t s0, uint64_t s1, uint32_t value, uint32_t lid = threadIdx.x,
+                                  uint32_t team = ET) {
     gptr<uint8_t> base = as_global(pg.dst);
     const uint64_t b0 = s0 * ELEM, b1 = s1 * ELEM;
     uint64_t a0 = (((uintptr_t)(pg.dst + b0) + 15) & ~(uintptr_t)15) - (uintptr_t)pg.dst; // first 16-byte boundary at or after b0
@@ -410,11 +411,11 @@ __device__ inline void fill_dense(const DevPage& pg, uint64_t s0, uint64_t s1, u
     const uint64_t a1 = a0 + ((b1 - a0) & ~(uint64_t)15);
     const uint32_t w = ELEM == 1 ? (value & 0xff) * 0x01010101u : value;
     u32x4 v = {w, w, w, w};
-    for (uint64_t c = a0 + (uint64_t)threadIdx.x * 16; c < a1; c += (uint64_t)ET * 16) *(gptr<u32x4>)(base + c) = v;
-    for (uint64_t c = b0 + (uint64_t)threadIdx.x * ELEM; c < a0; c += (uint64_t)ET * ELEM) {
+    for (uint64_t c = a0 + (uint64_t)lid * 16; c < a1; c += (uint64_t)team * 16) *(gptr<u32x4>)(base + c) = v;
+    for (uint64_t c = b0 + (uint64_t)lid * ELEM; c < a0; c += (uint64_t)team * ELEM) {
         if (ELEM == 1) base[c] = (uint8_t)value; else *(gptr<uint32_t>)(base + c) = value;
     }
-    for (uint64_t c = a1 + (uint64_t)threadIdx.x * ELEM; c < b1; c += (uint64_t)ET * ELEM) {
+    for (uint64_t c = a1 + (uint64_t)lid * ELEM; c < b1; c += (uint64_t)team * ELEM) {
         if (ELEM == 1) base[c] = (uint8_t)value; else *(gptr<uint32_t>)(base + c) = value;
     }
 }
@@ -586,6 +587,115 @@ __device__ inline void expand_tile(EShared& sh, const DevPage& pg, DevResult* re
     }
 }
 
+// One-byte outputs (levels, booleans): a whole group of steps at once.  The runs that meet the
+// group are copied to LDS in one go, the packed bytes of all its bit-packed runs in another,
+// and the runs are then expanded one after the other out of LDS: three dependent round trips
+// to memory per workgroup instead of three per run.  Returns false when the group does not
+// fit these buffers; the caller then takes it step by step.
+constexpr uint32_t RT_CAP = MAX_TILE_RUNS * 4 / 16; // run-table entries the run_start buffer can hold instead
+constexpr uint32_t GROUP_SHORT_RUN = 1024;          // runs of at most this many values are expanded by one wavefront
+constexpr uint32_t GROUP_STAGE_PAD = 16;           // bytes left free before the staged packed data
+
+__device__ inline bool expand_group_bytes(EShared& sh, const DevPage& pg, uint64_t G0, uint32_t GN, uint64_t total,
+                                          uint64_t n_runs, uint32_t bw) {
+    const uint32_t tid = threadIdx.x;
+    gptr<const uint8_t> src = as_global(pg.src);
+    gptr<uint8_t> dst = as_global(pg.dst);
+    gptr<const Run> runs = as_global((const Run*)pg.runs);
+    if (G0 >= total) return true; // nothing of the stream reaches this group
+    const uint32_t GS = total - G0 < GN ? (uint32_t)(total - G0) : GN;
+    u32x4* tab = reinterpret_cast<u32x4*>(sh.run_start);
+    const uint64_t r_first = n_runs > 1 ? as_global((const uint32_t*)pg.tile_run)[G0 / RLE_TILE] : 0;
+    const uint32_t K = n_runs - r_first < RT_CAP ? (uint32_t)(n_runs - r_first) : RT_CAP;
+    for (uint32_t k = tid; k < K; k += ET) tab[k] = *(gptr<const u32x4>)(runs + r_first + k);
+    if (tid == 0) { sh.first_idx[0] = 0xffffffffu; sh.first_idx[1] = 0; } // byte range of the packed data: lo, hi
+    __syncthreads();
+    // runs that start before the end of the group
+    uint32_t nr;
+    {
+        uint32_t lo = 0, hi = K;
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if ((uint64_t)tab[mid].x < G0 + GS) lo = mid; else hi = mid;
+        }
+        nr = lo + 1;
+    }
+    {
+        const u32x4 last = tab[nr - 1];
+        if ((uint64_t)last.x + (last.w >> 1) < G0 + GS) return false; // the group runs past the staged entries
+    }
+    for (uint32_t k = tid; k < nr; k += ET) {
+        const u32x4 r = tab[k];
+        if (r.w & 1) {
+            const uint64_t rb = r.x, re = rb + (r.w >> 1);
+            const uint64_t s0 = rb > G0 ? rb : G0, s1 = re < G0 + GS ? re : G0 + GS;
+            if (s1 > s0) {
+                atomicMin(&sh.first_idx[0], r.y + (uint32_t)(((s0 - rb) * bw) >> 3));
+                atomicMax(&sh.first_idx[1], r.y + (uint32_t)(((s1 - rb) * bw + 7) >> 3));
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t b_lo = sh.first_idx[0], b_hi = sh.first_idx[1];
+    int64_t base = 0; // src offset of stage byte 0: up to 15 bytes before the first packed byte, so the loads are aligned
+    if (b_hi > b_lo && b_lo != 0xffffffffu) {
+        base = (int64_t)b_lo - (int64_t)((uintptr_t)(pg.src + b_lo) & 15);
+        const uint32_t span = (uint32_t)((int64_t)b_hi - base);
+        if (span > STAGE_BYTES - 64 - GROUP_STAGE_PAD) { __syncthreads(); return false; }
+        for (uint32_t c = tid * 16; c < span; c += ET * 16)
+            *reinterpret_cast<u32x4*>(&sh.stage[(c + GROUP_STAGE_PAD) >> 2]) = *(gptr<const u32x4>)(src + base + c);
+    }
+    __syncthreads();
+    // Long runs are shared by the whole workgroup, short ones are dealt out to the wavefronts:
+    // no run waits for another, they write disjoint parts of the destination.
+    const uint32_t mask = (1u << bw) - 1;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (uint32_t k = 0; k < nr; k++) {
+        const u32x4 r = tab[k];
+        const uint64_t rb = r.x, re = rb + (r.w >> 1);
+        const uint64_t s0 = rb > G0 ? rb : G0, s1 = re < G0 + GS ? re : G0 + GS;
+        if (s1 <= s0) continue;
+        const uint32_t sn = (uint32_t)(s1 - s0);
+        const bool shared = sn > GROUP_SHORT_RUN;
+        if (!shared && (k & 3) != wave) continue;
+        const uint32_t lid = shared ? tid : (tid & 63), team = shared ? ET : 64;
+        if (!(r.w & 1)) { fill_dense<1>(pg, s0, s1, r.z, lid, team); continue; }
+        const uint64_t skip = (s0 - rb) * bw; // bits of the run before this group
+        const uint32_t bit_base = (uint32_t)((int64_t)r.y + (int64_t)(skip >> 3) - base + GROUP_STAGE_PAD) * 8 + (uint32_t)(skip & 7);
+        // Every lane owns eight values that start on an 8-byte boundary of the destination: its
+        // fields lie inside 96 bits from the dword the first one starts in.  At the ragged ends of
+        // the span the same window is cut out (it may start before the first field: the staged
+        // bytes sit GROUP_STAGE_PAD bytes into the buffer) and only the values inside are stored.
+        const uint32_t a = (uint32_t)((uintptr_t)(pg.dst + s0) & 7);
+        for (uint32_t c = lid * 8; c < sn + a; c += team * 8) {
+            const int32_t j0 = (int32_t)c - (int32_t)a;
+            const uint32_t b = bit_base + (uint32_t)(j0 * (int32_t)bw);
+            const uint32_t d = b >> 5;
+            const uint32_t w0 = sh.stage[d], w1 = sh.stage[d + 1], w2 = sh.stage[d + 2];
+            const uint64_t w01 = (uint64_t)w0 | ((uint64_t)w1 << 32);
+            const uint64_t w12 = (uint64_t)w1 | ((uint64_t)w2 << 32);
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t e = 0; e < 8; e++) {
+                const uint32_t off = (b & 31) + e * bw;
+                v[e] = (uint32_t)(off < 32 ? w01 >> off : w12 >> (off - 32)) & mask;
+            }
+            gptr<uint8_t> o = dst + (s0 + (uint64_t)(int64_t)j0);
+            if (j0 >= 0 && (uint32_t)j0 + 8 <= sn) {
+                u32x2 w;
+                w.x = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+                w.y = v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24);
+                *(gptr<u32x2>)(o) = w;
+            } else {
+#pragma unroll
+                for (uint32_t e = 0; e < 8; e++)
+                    if ((uint32_t)(j0 + (int32_t)e) < sn) o[e] = (uint8_t)v[e]; // unsigned: values before the span fail too
+            }
+        }
+    }
+    return true;
+}
+
 __global__ __launch_bounds__(ET) void rle_expand_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
                                                        const uint32_t* __restrict__ items, uint32_t n_items,
                                                        const uint64_t* __restrict__ tile_prefix,
@@ -622,6 +732,13 @@ __global__ __launch_bounds__(ET) void rle_expand_kernel(const DevPage* __restric
         res->out_values = n_out;
         res->out_bytes = n_out == 0 ? 0 : (n_out - 1) * (uint64_t)stride + elem;
         if (too_small && res->status == PQD_OK) { res->status = PQD_ERR_DST_TOO_SMALL; res->arg = (int64_t)need_bytes; }
+    }
+    if (group > 1 && !fused && elem == 1 && stride == 1 && bw <= 8) {
+        const uint64_t G0 = tile * group * (uint64_t)RLE_TILE;
+        if (G0 >= n_out) return;
+        const uint32_t GN = n_out - G0 < (uint64_t)group * RLE_TILE ? (uint32_t)(n_out - G0) : group * RLE_TILE;
+        if (expand_group_bytes(sh, pg, G0, GN, total, n_runs, bw)) return;
+        __syncthreads();
     }
     // the first run of every step, fetched together: one round trip instead of two per step
     if (threadIdx.x < group) {
