@@ -41,10 +41,10 @@ struct pqd_batch {
     DevPage* d_items = nullptr;
     DevResult* d_results = nullptr;
     FamilyList fam[16];
-    // RLE expand grid
-    uint64_t* d_rle_tile_prefix = nullptr;
-    uint32_t* d_rle_tile_item = nullptr; // grid tile -> position in the family list (null: the kernel searches the prefix)
-    uint64_t rle_tiles = 0;
+    // RLE expand grids, one per RLE hybrid family
+    uint64_t* d_rle_tile_prefix[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t* d_rle_tile_item[4] = {nullptr, nullptr, nullptr, nullptr}; // grid tile -> position in the family list (null: the kernel searches the prefix)
+    uint64_t rle_tiles[4] = {0, 0, 0, 0};
     uint64_t rle_steps = 0;
     // generic tile grids for the element-parallel families
     uint64_t max_src[16] = {0}; // longest src of each family, sizes the tile grids
@@ -80,6 +80,15 @@ int32_t elem_width_of(int32_t kind, int32_t bit_width) {
 
 // Which kernel family decodes (encoding, kind); FAM_NONE = not supported, as
 // encoding.NotSupported would answer (encoding/notsupported.go:163-197).
+// The RLE hybrid families share the index kernel; each has an expand kernel and a tile grid of its own.
+constexpr int RLE_GRIDS = 4;
+constexpr int32_t RLE_FAMILY[RLE_GRIDS] = {FAM_RLE, FAM_RLE_BYTES, FAM_RLE_DICT8, FAM_RLE_DICT4};
+inline int rle_grid(int32_t family) {
+    for (int g = 0; g < RLE_GRIDS; g++) if (RLE_FAMILY[g] == family) return g;
+    return -1;
+}
+inline bool is_rle(int32_t family) { return rle_grid(family) >= 0; }
+
 int32_t classify(const pqd_page& p) {
     const int32_t e = p.encoding, k = p.kind;
     switch (e) {
@@ -88,7 +97,8 @@ int32_t classify(const pqd_page& p) {
             if (k == PQD_KIND_INT64) return FAM_DELTA64;
             return FAM_NONE;
         case PQD_ENC_RLE:
-            if (k == PQD_KIND_LEVELS || k == PQD_KIND_INT32 || k == PQD_KIND_BOOLEAN) return FAM_RLE;
+            if (k == PQD_KIND_INT32) return FAM_RLE;
+            if (k == PQD_KIND_LEVELS || k == PQD_KIND_BOOLEAN) return FAM_RLE_BYTES;
             return FAM_NONE;
         case PQD_ENC_RLE_DICTIONARY:
         case PQD_ENC_PLAIN_DICTIONARY:
@@ -212,11 +222,13 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
         } else if (family == FAM_DELTA32 || family == FAM_DELTA64) {
             m.primary = (int32_t)b->items.size();
             b->items.push_back(make_item(p, family));
-        } else if (family == FAM_RLE) {
+        } else if (is_rle(family)) {
             DevPage d = make_item(p, family);
             const bool dict_enc = p.encoding == PQD_ENC_RLE_DICTIONARY || p.encoding == PQD_ENC_PLAIN_DICTIONARY;
             d.fused = (dict_enc && (p.dict != nullptr || p.dict_len > 0)) ? 1 : 0;
             if (!d.fused && dict_enc) d.elem_width = 4;
+            if (d.fused && d.elem_width == 8) d.family = FAM_RLE_DICT8;
+            if (d.fused && d.elem_width == 4) d.family = FAM_RLE_DICT4;
             d.runs_cap = p.src_len + 1;
             runs_entries += d.runs_cap;
             m.primary = (int32_t)b->items.size();
@@ -276,30 +288,33 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
         b->map[i] = m;
     }
 
-    // ---- family lists and the RLE tile grid ----
-    std::vector<uint64_t> rle_prefix;
+    // ---- family lists and the RLE tile grids ----
+    std::vector<uint64_t> rle_prefix[RLE_GRIDS];
     for (uint32_t k = 0; k < b->items.size(); k++) {
         DevPage& d = b->items[k];
         b->fam[d.family].items.push_back(k);
         b->max_src[d.family] = std::max<uint64_t>(b->max_src[d.family], d.src_len);
-        if (d.family == FAM_RLE) {
+        if (is_rle(d.family)) {
+            const int g = rle_grid(d.family);
             const uint64_t stride = d.dst_stride > 0 ? (uint64_t)d.dst_stride : (uint64_t)d.elem_width;
             uint64_t bound = stride ? d.dst_cap / stride + 1 : 0;
             if (d.num_values >= 0 && (uint64_t)d.num_values < bound) bound = (uint64_t)d.num_values;
             const uint64_t steps = std::max<uint64_t>(1, (bound + RLE_TILE - 1) / RLE_TILE);
             if (steps > 0x7fffffffull) { delete b; return PQD_ERR_INVALID_ARGUMENT; }
-            d.group = d.elem_width == 1 ? 8 : 1; // 1-byte elements: 2 KB per step is too little work for a workgroup
+            d.group = d.family == FAM_RLE_BYTES ? 8 : 1; // 1-byte elements: 2 KB per step is too little work for a workgroup
             d.n_steps = (uint32_t)steps;
             const uint64_t tiles = (steps + d.group - 1) / d.group;
-            rle_prefix.push_back(b->rle_tiles);
-            d.tile_base = b->rle_tiles;
+            rle_prefix[g].push_back(b->rle_tiles[g]);
+            d.tile_base = b->rle_tiles[g];
             d.lengths_cap = b->rle_steps; // offset of this page in the tile_run array (pointer set after the carve)
-            b->rle_tiles += tiles;
+            b->rle_tiles[g] += tiles;
             b->rle_steps += steps;
         }
     }
-    rle_prefix.push_back(b->rle_tiles);
-    if (b->rle_tiles > 0x7fffffffull) { delete b; return PQD_ERR_INVALID_ARGUMENT; }
+    for (int g = 0; g < RLE_GRIDS; g++) {
+        rle_prefix[g].push_back(b->rle_tiles[g]);
+        if (b->rle_tiles[g] > 0x7fffffffull) { delete b; return PQD_ERR_INVALID_ARGUMENT; }
+    }
 
     // ---- carve one arena ----
     const size_t n_items = b->items.size();
@@ -309,9 +324,13 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
     const size_t o_results = carve(n_items * sizeof(DevResult));
     size_t o_fam[16];
     for (int f = 0; f < 16; f++) o_fam[f] = carve(b->fam[f].items.size() * sizeof(uint32_t));
-    const size_t o_rle_prefix = carve(rle_prefix.size() * sizeof(uint64_t));
-    const bool with_tile_item = b->rle_tiles <= (1ull << 24);
-    const size_t o_rle_tile_item = carve(with_tile_item ? b->rle_tiles * sizeof(uint32_t) : 0);
+    size_t o_rle_prefix[RLE_GRIDS], o_rle_tile_item[RLE_GRIDS];
+    bool with_tile_item[RLE_GRIDS];
+    for (int g = 0; g < RLE_GRIDS; g++) {
+        o_rle_prefix[g] = carve(rle_prefix[g].size() * sizeof(uint64_t));
+        with_tile_item[g] = b->rle_tiles[g] <= (1ull << 24);
+        o_rle_tile_item[g] = carve(with_tile_item[g] ? b->rle_tiles[g] * sizeof(uint32_t) : 0);
+    }
     const size_t o_rle_tile_run = carve(b->rle_steps * sizeof(uint32_t));
     const size_t o_runs = carve(runs_entries * sizeof(Run));
     const size_t o_lengths = carve(lengths_entries * sizeof(int32_t));
@@ -320,12 +339,14 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
     uint8_t* a = static_cast<uint8_t*>(b->arena);
     b->d_items = reinterpret_cast<DevPage*>(a + o_items);
     b->d_results = reinterpret_cast<DevResult*>(a + o_results);
-    b->d_rle_tile_prefix = reinterpret_cast<uint64_t*>(a + o_rle_prefix);
-    b->d_rle_tile_item = with_tile_item ? reinterpret_cast<uint32_t*>(a + o_rle_tile_item) : nullptr;
+    for (int g = 0; g < RLE_GRIDS; g++) {
+        b->d_rle_tile_prefix[g] = reinterpret_cast<uint64_t*>(a + o_rle_prefix[g]);
+        b->d_rle_tile_item[g] = with_tile_item[g] ? reinterpret_cast<uint32_t*>(a + o_rle_tile_item[g]) : nullptr;
+    }
     Run* runs = reinterpret_cast<Run*>(a + o_runs);
     int32_t* lengths = reinterpret_cast<int32_t*>(a + o_lengths);
     for (DevPage& d : b->items) {
-        if (d.family == FAM_RLE) {
+        if (is_rle(d.family)) {
             d.runs = runs; runs += d.runs_cap;
             d.tile_run = reinterpret_cast<uint32_t*>(a + o_rle_tile_run) + d.lengths_cap;
             d.lengths_cap = 0;
@@ -352,13 +373,16 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
             ok = ok && hip_ok(hipMemcpy(b->fam[f].dev, b->fam[f].items.data(), b->fam[f].items.size() * sizeof(uint32_t),
                                         hipMemcpyHostToDevice));
     }
-    ok = ok && hip_ok(hipMemcpy(b->d_rle_tile_prefix, rle_prefix.data(), rle_prefix.size() * sizeof(uint64_t),
-                                hipMemcpyHostToDevice));
-    if (with_tile_item && b->rle_tiles > 0) {
-        std::vector<uint32_t> tile_item(b->rle_tiles);
-        for (size_t k = 0; k + 1 < rle_prefix.size(); k++)
-            std::fill(tile_item.begin() + rle_prefix[k], tile_item.begin() + rle_prefix[k + 1], (uint32_t)k);
-        ok = ok && hip_ok(hipMemcpy(b->d_rle_tile_item, tile_item.data(), tile_item.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    for (int g = 0; g < RLE_GRIDS; g++) {
+        ok = ok && hip_ok(hipMemcpy(b->d_rle_tile_prefix[g], rle_prefix[g].data(), rle_prefix[g].size() * sizeof(uint64_t),
+                                    hipMemcpyHostToDevice));
+        if (with_tile_item[g] && b->rle_tiles[g] > 0) {
+            std::vector<uint32_t> tile_item(b->rle_tiles[g]);
+            for (size_t k = 0; k + 1 < rle_prefix[g].size(); k++)
+                std::fill(tile_item.begin() + rle_prefix[g][k], tile_item.begin() + rle_prefix[g][k + 1], (uint32_t)k);
+            ok = ok && hip_ok(hipMemcpy(b->d_rle_tile_item[g], tile_item.data(), tile_item.size() * sizeof(uint32_t),
+                                        hipMemcpyHostToDevice));
+        }
     }
     if (!ok) { (void)hipFree(b->arena); delete b; return PQD_ERR_DEVICE; }
     b->h_results.resize(n_items);
@@ -372,9 +396,15 @@ int pqd_batch_launch(pqd_batch* b, void* hip_stream) {
     launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA32].dev, (uint32_t)b->fam[FAM_DELTA32].items.size(), false, s);
     launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA32_CHAINED].dev, (uint32_t)b->fam[FAM_DELTA32_CHAINED].items.size(), false, s);
     launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA64].dev, (uint32_t)b->fam[FAM_DELTA64].items.size(), true, s);
-    launch_rle_index(b->d_items, b->d_results, b->fam[FAM_RLE].dev, (uint32_t)b->fam[FAM_RLE].items.size(), s);
-    launch_rle_expand(b->d_items, b->d_results, b->fam[FAM_RLE].dev, (uint32_t)b->fam[FAM_RLE].items.size(),
-                      b->d_rle_tile_prefix, b->d_rle_tile_item, b->rle_tiles, s);
+    for (int g = 0; g < RLE_GRIDS; g++) {
+        const FamilyList& f = b->fam[RLE_FAMILY[g]];
+        launch_rle_index(b->d_items, b->d_results, f.dev, (uint32_t)f.items.size(), s);
+    }
+    for (int g = 0; g < RLE_GRIDS; g++) {
+        const FamilyList& f = b->fam[RLE_FAMILY[g]];
+        launch_rle_expand(b->d_items, b->d_results, f.dev, (uint32_t)f.items.size(), b->d_rle_tile_prefix[g], b->d_rle_tile_item[g],
+                          b->rle_tiles[g], RLE_FAMILY[g], s);
+    }
     auto fam_n = [&](int f) { return (uint32_t)b->fam[f].items.size(); };
     launch_bitpacked(b->d_items, b->d_results, b->fam[FAM_BITPACKED].dev, fam_n(FAM_BITPACKED), b->max_src[FAM_BITPACKED] * 8, s);
     launch_bss(b->d_items, b->d_results, b->fam[FAM_BSS].dev, fam_n(FAM_BSS), b->max_src[FAM_BSS], s);
@@ -408,7 +438,7 @@ int pqd_batch_finish(pqd_batch* b, void* hip_stream, pqd_page* pages, uint64_t n
         p.out_values = r.out_values;
         p.out_bytes = r.out_bytes;
         p.consumed = r.consumed;
-        if (d.family == FAM_RLE && d.fused && r.status == PQD_OK && r.aux != ~0ull) {
+        if (is_rle(d.family) && d.fused && r.status == PQD_OK && r.aux != ~0ull) {
             p.status = PQD_ERR_INDEX_OUT_OF_BOUNDS; // the reference panics here (errors.go:75-83)
             p.status_arg = (int64_t)r.aux;
         }

@@ -75,8 +75,8 @@ enum Family : int32_t {
     FAM_NONE = 0,
     FAM_DELTA32 = 1,
     FAM_DELTA64 = 2,
-    FAM_RLE = 3,        // levels, int32, fused dictionary
-    FAM_RLE_BOOL = 4,
+    FAM_RLE = 3,        // RLE hybrid to 4-byte values or through a dictionary of 12-byte values
+    FAM_RLE_BYTES = 4,  // RLE hybrid to one byte per element: levels, booleans
     FAM_BITPACKED = 5,
     FAM_BSS = 6,
     FAM_PLAIN_FIXED = 7,
@@ -84,7 +84,9 @@ enum Family : int32_t {
     FAM_DLBA = 9,
     FAM_DBA = 10,
     FAM_ERROR = 11,     // rejected on the host; status already set
-    FAM_DELTA32_CHAINED = 12 // a length stream that starts where another item's stream ended
+    FAM_DELTA32_CHAINED = 12, // a length stream that starts where another item's stream ended
+    FAM_RLE_DICT8 = 13, // RLE hybrid through a dictionary of 8-byte values
+    FAM_RLE_DICT4 = 14  // ... of 4-byte values
 };
 
 // Pointers read out of a descriptor are generic to the compiler, which then
@@ -149,7 +151,7 @@ void launch_delta(const DevPage* pages, DevResult* results, const uint32_t* item
 void launch_rle_index(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
                       hipStream_t stream);
 void launch_rle_expand(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
-                       const uint64_t* tile_prefix, const uint32_t* tile_item, uint64_t n_tiles, hipStream_t stream);
+                       const uint64_t* tile_prefix, const uint32_t* tile_item, uint64_t n_tiles, int32_t family, hipStream_t stream);
 
 void launch_bitpacked(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_values,
                       hipStream_t stream);

@@ -696,7 +696,12 @@ __device__ inline bool expand_group_bytes(EShared& sh, const DevPage& pg, uint64
     return true;
 }
 
-__global__ __launch_bounds__(ET) void rle_expand_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+// One instantiation per RLE hybrid family, so that each carries only the code and the registers
+// of its own element type: FAM_RLE_BYTES one byte per element (levels, booleans), FAM_RLE_DICT8 /
+// FAM_RLE_DICT4 through a dictionary of 8- / 4-byte values, FAM_RLE the rest (4-byte values,
+// 12-byte dictionary entries).
+template <int FAMILY>
+__global__ __launch_bounds__(ET) __attribute__((amdgpu_waves_per_eu(FAMILY == FAM_RLE_BYTES ? 8 : 4, 8))) void rle_expand_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
                                                        const uint32_t* __restrict__ items, uint32_t n_items,
                                                        const uint64_t* __restrict__ tile_prefix,
                                                        const uint32_t* __restrict__ tile_item) {
@@ -733,7 +738,7 @@ __global__ __launch_bounds__(ET) void rle_expand_kernel(const DevPage* __restric
         res->out_bytes = n_out == 0 ? 0 : (n_out - 1) * (uint64_t)stride + elem;
         if (too_small && res->status == PQD_OK) { res->status = PQD_ERR_DST_TOO_SMALL; res->arg = (int64_t)need_bytes; }
     }
-    if (group > 1 && !fused && elem == 1 && stride == 1 && bw <= 8) {
+    if (FAMILY == FAM_RLE_BYTES && group > 1 && !fused && elem == 1 && stride == 1 && bw <= 8) {
         const uint64_t G0 = tile * group * (uint64_t)RLE_TILE;
         if (G0 >= n_out) return;
         const uint32_t GN = n_out - G0 < (uint64_t)group * RLE_TILE ? (uint32_t)(n_out - G0) : group * RLE_TILE;
@@ -761,17 +766,11 @@ __global__ __launch_bounds__(ET) void rle_expand_kernel(const DevPage* __restric
         Run first;
         first.out_start = fw.x; first.in_off = fw.y; first.value = fw.z; first.count_kind = fw.w;
         const uint32_t n = n_out - t0 < RLE_TILE ? (uint32_t)(n_out - t0) : RLE_TILE;
-        if (fused) {
-            switch (elem) {
-                case 4: expand_tile<4, true>(sh, pg, res, t0, n, total, n_runs, bw, r0, first); break;
-                case 8: expand_tile<8, true>(sh, pg, res, t0, n, total, n_runs, bw, r0, first); break;
-                default: expand_tile<12, true>(sh, pg, res, t0, n, total, n_runs, bw, r0, first); break;
-            }
-        } else if (elem == 1) {
-            expand_tile<1, false>(sh, pg, res, t0, n, total, n_runs, bw, r0, first);
-        } else {
-            expand_tile<4, false>(sh, pg, res, t0, n, total, n_runs, bw, r0, first);
-        }
+        if (FAMILY == FAM_RLE_BYTES) expand_tile<1, false>(sh, pg, res, t0, n, total, n_runs, bw, r0, first);
+        else if (FAMILY == FAM_RLE_DICT8) expand_tile<8, true>(sh, pg, res, t0, n, total, n_runs, bw, r0, first);
+        else if (FAMILY == FAM_RLE_DICT4) expand_tile<4, true>(sh, pg, res, t0, n, total, n_runs, bw, r0, first);
+        else if (fused) expand_tile<12, true>(sh, pg, res, t0, n, total, n_runs, bw, r0, first);
+        else expand_tile<4, false>(sh, pg, res, t0, n, total, n_runs, bw, r0, first);
         if (step + 1 < group) __syncthreads(); // the next step restages the LDS buffers
     }
 }
@@ -785,10 +784,24 @@ void launch_rle_index(const DevPage* pages, DevResult* results, const uint32_t* 
 }
 
 void launch_rle_expand(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
-                       const uint64_t* tile_prefix, const uint32_t* tile_item, uint64_t n_tiles, hipStream_t stream) {
+                       const uint64_t* tile_prefix, const uint32_t* tile_item, uint64_t n_tiles, int32_t family,
+                       hipStream_t stream) {
     if (n_items == 0 || n_tiles == 0) return;
-    hipLaunchKernelGGL(rle_expand_kernel, dim3((uint32_t)n_tiles), dim3(ET), 0, stream, pages, results, items, n_items,
-                       tile_prefix, tile_item);
+    const dim3 grid((uint32_t)n_tiles), block(ET);
+    switch (family) {
+        case FAM_RLE_BYTES:
+            hipLaunchKernelGGL(rle_expand_kernel<FAM_RLE_BYTES>, grid, block, 0, stream, pages, results, items, n_items, tile_prefix, tile_item);
+            break;
+        case FAM_RLE_DICT8:
+            hipLaunchKernelGGL(rle_expand_kernel<FAM_RLE_DICT8>, grid, block, 0, stream, pages, results, items, n_items, tile_prefix, tile_item);
+            break;
+        case FAM_RLE_DICT4:
+            hipLaunchKernelGGL(rle_expand_kernel<FAM_RLE_DICT4>, grid, block, 0, stream, pages, results, items, n_items, tile_prefix, tile_item);
+            break;
+        default:
+            hipLaunchKernelGGL(rle_expand_kernel<FAM_RLE>, grid, block, 0, stream, pages, results, items, n_items, tile_prefix, tile_item);
+            break;
+    }
 }
 
 } // namespace pqd
