@@ -90,15 +90,32 @@ __global__ __launch_bounds__(MT) void bitpacked_kernel(const DevPage* __restrict
     }
     const uint64_t tile = (uint64_t)MT * 16;
     for (uint64_t t = blockIdx.y; t * tile < count; t += gridDim.y) {
-        for (uint32_t q = 0; q < 4; q++) {
-            const uint64_t k = t * tile + (uint64_t)q * MT * 4 + threadIdx.x * 4;
-            if (k + 4 <= count && ((uintptr_t)(pg.dst + k) & 3) == 0) {
-                uint32_t w = 0;
-                for (uint32_t e = 0; e < 4; e++) w |= bitpacked_value(src, n, k + e, bw) << (8 * e);
-                *(gptr<uint32_t>)(dst + k) = w;
-            } else {
-                for (uint32_t e = 0; e < 4 && k + e < count; e++) dst[k + e] = (uint8_t)bitpacked_value(src, n, k + e, bw);
+        const uint64_t k = t * tile + (uint64_t)threadIdx.x * 16;
+        if (k >= count) continue;
+        // Sixteen values start on a byte boundary (16 * bw bits) and take 2 * bw bytes.  Widths up to 8
+        // with all sixteen bytes inside the page: one unaligned 16-byte load, read as a big-endian
+        // 128-bit number whose fields are cut out from the top; 16-byte store.
+        const uint64_t byte0 = 2 * (k / 16) * bw;
+        if (bw <= 8 && k + 16 <= count && byte0 + 16 <= n && ((uintptr_t)(pg.dst + k) & 3) == 0) {
+            const u32x4_a1 raw = *(gptr<const u32x4_a1>)(src + byte0);
+            const uint64_t hi = ((uint64_t)__builtin_bswap32(raw.x) << 32) | __builtin_bswap32(raw.y);
+            const uint64_t lo = ((uint64_t)__builtin_bswap32(raw.z) << 32) | __builtin_bswap32(raw.w);
+            const uint32_t mask = (1u << bw) - 1;
+            uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (uint32_t e = 0; e < 16; e++) {
+                const uint32_t end = (e + 1) * bw; // bits from the top of the 128 to the end of field e
+                uint64_t f;
+                if (end <= 64) f = hi >> (64 - end);
+                else if (end - bw >= 64) f = lo >> (128 - end);
+                else f = (hi << (end - 64)) | (lo >> (128 - end));
+                w[e / 4] |= ((uint32_t)f & mask) << (8 * (e % 4));
             }
+            u32x4_a4 o;
+            o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+            *(gptr<u32x4_a4>)(dst + k) = o;
+        } else {
+            for (uint32_t e = 0; e < 16 && k + e < count; e++) dst[k + e] = (uint8_t)bitpacked_value(src, n, k + e, bw);
         }
     }
     if (lead) finish(res, PQD_OK, 0, count, count, n);
