@@ -196,8 +196,7 @@ __device__ inline void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_b
 
 template <typename U, bool LDS_ONLY>
 __device__ inline U tile_values(const uint32_t* ring, uint64_t* wtot, const Slot s, uint32_t count, uint32_t within, U& carry,
-                                U (&r)[4]) {
-    const uint32_t tid = threadIdx.x;
+                                U (&r)[4], uint32_t tid = threadIdx.x) {
     const uint32_t lane = tid & 63, wave = tid >> 6;
     const uint32_t j = tid * 4;
     U v[4] = {0, 0, 0, 0};
@@ -284,11 +283,11 @@ __device__ inline void tile_store(gptr<U> out, uint64_t done, uint32_t count, co
 // done + TILE (r3 of the last thread) is written by the next tile, or by the
 // caller after the last tile.
 template <typename U>
-__device__ inline void tile_store_shifted_full(gptr<U> out, uint32_t done, U e, const U (&r)[4]) {
+__device__ inline void tile_store_shifted_full(gptr<U> out, uint32_t done, U e, const U (&r)[4], uint32_t tid = threadIdx.x) {
     const uint64_t ot = (uint64_t)(uintptr_t)out + (uint64_t)done * sizeof(U);
     const uint32_t ot_lo = __builtin_amdgcn_readfirstlane((uint32_t)ot);
     const uint32_t ot_hi = __builtin_amdgcn_readfirstlane((uint32_t)(ot >> 32));
-    gptr<U> o = (gptr<U>)(((uint64_t)ot_hi << 32) | ot_lo) + threadIdx.x * 4;
+    gptr<U> o = (gptr<U>)(((uint64_t)ot_hi << 32) | ot_lo) + tid * 4;
     if (sizeof(U) == 8) {
         u64x2_a8 a, b2;
         a.x = (uint64_t)e; a.y = (uint64_t)r[0];
@@ -339,6 +338,7 @@ constexpr uint32_t TBL_SLOTS = TBL_TILES * 32;  // miniblocks one walk can descr
 constexpr uint32_t TBL_BLOCKS = TBL_TILES * 8; // blocks one walk can describe
 constexpr uint32_t HDR_MAX = 10 + 32; // longest block header the fast path reads
 constexpr uint64_t FAST_MAX_BYTES = 0xfff00000ull; // pages the fast path addresses with 32-bit offsets
+constexpr uint32_t NO_POS = 0xffffffffu;
 
 // Everything below is in ring space (byte offsets from the 16-byte aligned
 // base of the page), 32 bits wide.
@@ -356,6 +356,7 @@ struct FastShared {
     uint32_t ring[RING_BYTES / 4 + 4]; // + mirror of the first 16 bytes, so a field never wraps
     Slot slots[TBL_SLOTS];
     uint32_t blk_end[TBL_BLOCKS];
+    uint32_t blk_pos[TBL_BLOCKS]; // where the walk found each block; NO_POS once its slots are written
     uint64_t wtot[DT / 64];
     Ctl ctl;
     FastCtl fc;
@@ -391,6 +392,41 @@ __device__ inline void ring_fill32(uint32_t* ring, gptr<const uint8_t> base, uin
         ring_put(ring, v, end, w);
         c_next++;
     }
+}
+
+
+// The sixteen bytes at ring position p, as two little-endian 64-bit halves.
+__device__ inline void ring_16(const uint32_t* ring, uint32_t p, uint64_t& lo, uint64_t& hi) {
+    const uint32_t d = (p & RING_MASK) >> 2, sh = (p & 3) * 8;
+    const uint32_t w0 = ring[d], w1 = ring[d + 1], w2 = ring[d + 2], w3 = ring[d + 3], w4 = ring[d + 4]; // the mirror covers d + 4
+    lo = ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, sh) << 32) | __builtin_amdgcn_alignbit(w1, w0, sh);
+    hi = ((uint64_t)__builtin_amdgcn_alignbit(w4, w3, sh) << 32) | __builtin_amdgcn_alignbit(w3, w2, sh);
+}
+
+// Header of a block with four miniblocks, out of sixteen bytes in registers: length of the
+// min-delta varint (Go's binary.Uvarint rules: at most ten bytes, the tenth at most 1) and the
+// four width bytes behind it.  False when the varint does not end or overflows.
+__device__ inline bool quick_header(uint64_t lo, uint64_t hi, uint32_t& k, uint32_t& widths) {
+    const uint64_t ends = ~lo & 0x8080808080808080ull; // bytes without a continuation bit
+    if (ends) k = ((uint32_t)__builtin_ctzll(ends) >> 3) + 1;
+    else if (!(hi & 0x80)) k = 9;
+    else if (!(hi & 0x8000) && ((hi >> 8) & 0xff) <= 1) k = 10;
+    else return false;
+    widths = k < 8 ? (uint32_t)((lo >> (8 * k)) | (hi << (64 - 8 * k))) : (uint32_t)(hi >> (8 * k - 64));
+    return true;
+}
+
+// The value of that varint (k bytes, k from quick_header).
+__device__ inline uint64_t quick_uvarint(uint64_t lo, uint64_t hi, uint32_t k) {
+    uint64_t x = lo & 0x7f7f7f7f7f7f7f7full;                                     // 8 x 7 bits in bytes
+    x = (x & 0x007f007f007f007full) | ((x & 0x7f007f007f007f00ull) >> 1);        // 4 x 14 bits in halves
+    x = (x & 0x00003fff00003fffull) | ((x & 0x3fff00003fff0000ull) >> 2);        // 2 x 28 bits in words
+    x = (x & 0x000000000fffffffull) | ((x & 0x0fffffff00000000ull) >> 4);        // 56 bits
+    if (k < 8) return x & ((1ull << (7 * k)) - 1);
+    if (k == 8) return x;
+    x |= (hi & 0x7f) << 56;
+    if (k == 10) x |= ((hi >> 8) & 1) << 63;
+    return x;
 }
 
 template <typename U>
@@ -455,7 +491,7 @@ void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict_
     uint32_t done = 0;
     const uint32_t n_deltas = total > 0 ? total - 1 : 0;
     uint32_t lo = (uint32_t)sh.ctl.lo;   // start of the next tile's bytes
-    uint32_t guess = 0;                  // wave 0: size of the last block walked
+    uint32_t guess = 0, alt = 0;         // wave 0: the block size the walk expects; the last size that differed
     uint32_t tbl_tiles = 0, tbl_next = 0, tbl_got = 0;
     __syncthreads();
 
@@ -481,24 +517,73 @@ void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict_
         if (tbl_next == tbl_tiles) {
             if (tid < 64) {
                 // ---- walk: block headers of up to TBL_TILES tiles, starting at lo ----
+                // the page geometry is re-read from LDS here, so that it does not occupy registers across the tile loop
+                const uint32_t w_vpm = sh.ctl.vpm, w_nmb = sh.ctl.slot_base, w_bs = sh.ctl.count;
+                const uint32_t w_vpm_shift = w_vpm ? 31 - __clz(w_vpm) : 0, w_blk_shift = w_bs ? 31 - __clz(w_bs) : 0;
+                const uint32_t w_nb_tile = w_bs ? TILE >> w_blk_shift : 1;
+                const uint32_t w_total = (uint32_t)sh.ctl.total;
+                const uint32_t w_n_deltas = w_total > 0 ? w_total - 1 : 0;
                 const uint32_t win_hi = (lo / CHUNK + LOOK / CHUNK + 1) * CHUNK; // resident bytes end here
-                const uint32_t rem = n_deltas - done;
-                const uint32_t blocks_left = (rem + block_size - 1) >> blk_shift;
-                const uint32_t target = blocks_left < TBL_TILES * nb_tile ? blocks_left : TBL_TILES * nb_tile;
-                const uint32_t enough = target < nb_tile ? target : nb_tile; // one tile, or what the page still has
+                const uint32_t rem = w_n_deltas - done;
+                const uint32_t blocks_left = (rem + w_bs - 1) >> w_blk_shift;
+                const uint32_t target = blocks_left < TBL_TILES * w_nb_tile ? blocks_left : TBL_TILES * w_nb_tile;
+                const uint32_t enough = target < w_nb_tile ? target : w_nb_tile; // one tile, or what the page still has
                 uint32_t pos = lo;
                 uint32_t found = 0, last_vals = 0;
                 int32_t wstatus = PQD_OK;
                 int64_t warg = 0;
                 bool ended = false;
-                while (found < enough) {
+                // One tile's blocks are always inside the resident window; the walk goes on past them,
+                // up to the whole table, for as long as the next header is.
+                while (found < target) {
+                    if (found >= enough && pos + HDR_MAX > win_hi && win_hi < end) break;
                     const uint32_t bidx = found + lane;
                     const uint32_t cand = pos + lane * guess;
                     const bool parsed = bidx < target && (lane == 0 || cand + HDR_MAX <= win_hi || win_hi >= end);
                     // values this block still has to deliver, and the miniblocks that hold them
-                    const uint32_t before = bidx << blk_shift;
-                    const uint32_t bvals = parsed ? (rem - before < block_size ? rem - before : block_size) : 0;
-                    const uint32_t need_mb = (bvals + vpm - 1) >> vpm_shift;
+                    const uint32_t before = bidx << w_blk_shift;
+                    const uint32_t bvals = parsed ? (rem - before < w_bs ? rem - before : w_bs) : 0;
+                    const uint32_t need_mb = (bvals + w_vpm - 1) >> w_vpm_shift;
+                    {
+                        // Quick round: only what the chain needs (the size of the block that would
+                        // start at cand), out of sixteen bytes in registers.  Blocks with four
+                        // miniblocks, all of them wanted, away from the end of the page; whatever
+                        // else heads the chain is left to the full parse below.
+                        bool quick = parsed && w_nmb == 4 && need_mb == 4 && cand + 16 <= end;
+                        uint32_t qsize = 0;
+                        if (quick) {
+                            uint64_t qlo, qhi;
+                            ring_16(sh.ring, cand, qlo, qhi);
+                            uint32_t k, wd;
+                            quick = quick_header(qlo, qhi, k, wd);
+                            const uint32_t b0 = wd & 0xff, b1 = (wd >> 8) & 0xff, b2 = (wd >> 16) & 0xff, b3 = wd >> 24;
+                            const uint32_t top = b0 > b1 ? (b0 > b2 ? (b0 > b3 ? b0 : b3) : (b2 > b3 ? b2 : b3))
+                                                         : (b1 > b2 ? (b1 > b3 ? b1 : b3) : (b2 > b3 ? b2 : b3));
+                            if (top > Elem<U>::max_bw) quick = false;
+                            qsize = k + 4 + (w_vpm >> 3) * (b0 + b1 + b2 + b3);
+                        }
+                        const unsigned long long qmask = __ballot(quick);
+                        if (qmask & 1) {
+                            const unsigned long long okmask = __ballot(quick && qsize == guess);
+                            const uint32_t lead = okmask == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~okmask);
+                            uint32_t valid = lead < 64 ? lead + (uint32_t)((qmask >> lead) & 1) : 64u;
+                            if (valid > target - found) valid = target - found;
+                            if (lane < valid) sh.blk_pos[bidx] = cand;
+                            const uint32_t last = valid - 1;
+                            const uint32_t l_size = lane_u32(qsize, last);
+                            found += valid;
+                            pos = lane_u32(cand, last) + l_size;
+                            // the size most blocks have stays the guess: an odd one (a varint one byte
+                            // longer, one narrower miniblock) is adopted only when it comes twice in a row
+                            if (l_size != guess) {
+                                if (guess == 0 || l_size == alt) guess = l_size;
+                                alt = l_size;
+                            }
+                            last_vals = lane_u32(bvals, last);
+                            continue;
+                        }
+                    }
+                    if (parsed) sh.blk_pos[bidx] = NO_POS; // the full parse writes the slots itself
                     int32_t err = PQD_OK;
                     int64_t err_arg = 0;
                     bool at_end = false;
@@ -514,7 +599,7 @@ void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict_
                             else {
                                 const int64_t md = unzigzag(z);
                                 const uint32_t wpos = cand + k;
-                                const uint32_t nbw = end - wpos < nmb ? end - wpos : nmb;
+                                const uint32_t nbw = end - wpos < w_nmb ? end - wpos : w_nmb;
                                 uint32_t off = wpos + nbw;
                                 have_mb = nbw < need_mb ? nbw : need_mb;
                                 for (uint32_t m = 0; m < have_mb; m++) {
@@ -522,8 +607,8 @@ void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict_
                                     if (bw > Elem<U>::max_bw) { err = PQD_ERR_INVALID_BIT_WIDTH; err_arg = bw; have_mb = m; break; }
                                     Slot sl;
                                     sl.min_delta = md; sl.off = off; sl.bw = bw;
-                                    sh.slots[bidx * nmb + m] = sl;
-                                    off += (vpm * bw) >> 3;
+                                    sh.slots[bidx * w_nmb + m] = sl;
+                                    off += (w_vpm * bw) >> 3;
                                 }
                                 size = off - cand;
                                 sh.blk_end[bidx] = off;
@@ -546,25 +631,43 @@ void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict_
                         break;
                     }
                     const uint32_t last = valid - 1;
-                    const uint32_t l_have = __shfl(have_mb, last);
-                    const uint32_t l_need = __shfl(need_mb, last);
-                    const uint32_t l_vals = __shfl(bvals, last);
-                    const uint32_t l_size = __shfl(size, last);
-                    const uint32_t l_cand = __shfl(cand, last);
+                    const uint32_t l_have = lane_u32(have_mb, last);
+                    const uint32_t l_need = lane_u32(need_mb, last);
+                    const uint32_t l_vals = lane_u32(bvals, last);
+                    const uint32_t l_size = lane_u32(size, last);
+                    const uint32_t l_cand = lane_u32(cand, last);
                     found += valid;
                     pos = l_cand + l_size;
                     guess = l_size;
-                    last_vals = l_have < l_need ? l_have << vpm_shift : l_vals;
+                    last_vals = l_have < l_need ? l_have << w_vpm_shift : l_vals;
                     if (l_have < l_need) { // the widths ran out: nothing follows this block
                         wstatus = PQD_ERR_MISSING_VALUES;
                         ended = true;
                         break;
                     }
                 }
+                // blocks found by quick rounds: every lane parses its block in full and writes its slots
+                if (lane < found && sh.blk_pos[lane] != NO_POS) {
+                    const uint32_t at = sh.blk_pos[lane];
+                    uint64_t qlo, qhi;
+                    ring_16(sh.ring, at, qlo, qhi);
+                    uint32_t k, wd;
+                    quick_header(qlo, qhi, k, wd);
+                    const int64_t md = unzigzag(quick_uvarint(qlo, qhi, k));
+                    uint32_t off = at + k + 4;
+#pragma unroll
+                    for (uint32_t m = 0; m < 4; m++) {
+                        Slot sl;
+                        sl.min_delta = md; sl.off = off; sl.bw = (wd >> (8 * m)) & 0xff;
+                        sh.slots[lane * 4 + m] = sl;
+                        off += (w_vpm >> 3) * sl.bw;
+                    }
+                    sh.blk_end[lane] = off;
+                }
                 // keep whole tiles unless the stream or the page ends inside the table
                 const bool page_end = found == blocks_left && !ended;
-                if (!ended && !page_end) found = (found / nb_tile) * nb_tile;
-                const uint32_t got = found ? ((found - 1) << blk_shift) + (found == blocks_left || ended ? last_vals : block_size) : 0;
+                if (!ended && !page_end) found = (found / w_nb_tile) * w_nb_tile;
+                const uint32_t got = found ? ((found - 1) << w_blk_shift) + (found == blocks_left || ended ? last_vals : w_bs) : 0;
                 const uint32_t tiles = (got + TILE - 1) / TILE;
                 if (tid == 0) {
                     FastCtl& f = sh.fc;
@@ -572,7 +675,7 @@ void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict_
                     f.got = got;
                     f.tile_lo[0] = lo;
                     for (uint32_t t = 1; t <= tiles; t++) {
-                        uint32_t lastblk = t * nb_tile < found ? t * nb_tile : found;
+                        uint32_t lastblk = t * w_nb_tile < found ? t * w_nb_tile : found;
                         f.tile_lo[t] = sh.blk_end[lastblk - 1];
                     }
                     const uint32_t fin = found ? sh.blk_end[found - 1] : lo;
@@ -592,9 +695,13 @@ void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict_
             }
         }
 
+        // The thread number, opaque to the optimiser from here on: whatever the tile derives from it is
+        // computed again per tile (a few instructions) instead of being kept in registers across the walk.
+        uint32_t tq = tid;
+        asm volatile("" : "+v"(tq));
         const uint32_t left = tbl_got - tbl_next * TILE;
         const uint32_t count = left < TILE ? left : TILE;
-        const uint32_t j = tid * 4;
+        const uint32_t j = tq * 4;
         const uint32_t slot = tbl_next * slots_tile + (j >> vpm_shift);
         U r[4];
         if (count < TILE) {
@@ -616,15 +723,15 @@ void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict_
         const uint32_t lo_next = sh.fc.tile_lo[tbl_next + 1];
         const uint32_t c_want = lo_next / CHUNK + LOOK / CHUNK; // last chunk the next tile wants
         pf_n = c_next > c_want ? 0u : (c_want + 1 - c_next > 2 ? 2u : c_want + 1 - c_next);
-        pf_v = c_next * CHUNK + tid * 16u;
+        pf_v = c_next * CHUNK + tq * 16u;
         {
             const uint32_t pv1 = pf_v + CHUNK;
             pf0 = *(gptr<const u32x4>)(base + (pf_n > 0 && pf_v < end ? pf_v : 0u));
             pf1 = *(gptr<const u32x4>)(base + (pf_n > 1 && pv1 < end ? pv1 : 0u));
         }
 
-        const U e = tile_values<U, true>(sh.ring, sh.wtot, sh.slots[slot], TILE, j & (vpm - 1), carry, r);
-        tile_store_shifted_full<U>(out, done, e, r);
+        const U e = tile_values<U, true>(sh.ring, sh.wtot, sh.slots[slot], TILE, j & (vpm - 1), carry, r, tq);
+        tile_store_shifted_full<U>(out, done, e, r, tq);
         done += count;
         tbl_next++;
         lo = lo_next;

@@ -98,9 +98,11 @@ def plain_ba_page(vals):
 ONLY = os.environ.get("PQD_RATES_ONLY", "")  # run only the lines whose name contains this
 
 
-def run(name, pages_bytes, replicate, encoding, kind, bit_width, out_bytes_per_page, offsets_per_page, expect, steps=20):
+def run(name, pages_bytes, replicate, encoding, kind, bit_width, out_bytes_per_page, offsets_per_page, expect, steps=20,
+        dictionary=None, num_values=-1):
     if ONLY and ONLY not in name:
         return
+    dict_t = torch.from_numpy(dictionary.copy()).to(DEV) if dictionary is not None else None
     uniq = len(pages_bytes)
     slot = max((len(p) + 255) // 256 * 256 for p in pages_bytes) + 256
     n_pages = uniq * replicate
@@ -118,8 +120,10 @@ def run(name, pages_bytes, replicate, encoding, kind, bit_width, out_bytes_per_p
         p.dst, p.dst_cap = dst.data_ptr() + i * oslot, oslot - 256
         if off is not None:
             p.offsets, p.offsets_cap = off.data_ptr() + i * (offsets_per_page + 8) * 4, offsets_per_page + 8
-        p.num_values = -1
+        p.num_values = num_values
         p.encoding, p.kind, p.bit_width = encoding, kind, bit_width
+        if dict_t is not None:
+            p.dict, p.dict_len = dict_t.data_ptr(), dictionary.size
         pages.append(p)
     batch = pkg.Batch(ctx, pages)
     batch.launch(stream)
@@ -136,11 +140,12 @@ def run(name, pages_bytes, replicate, encoding, kind, bit_width, out_bytes_per_p
             batch.launch(s)
     wall, kms = bench.time_steps(S, torch, W(), stream, steps, 3, None)
     t = float(np.mean(kms)) / 1e3
-    enc_b = sum(len(pages_bytes[i % uniq]) for i in range(n_pages))
+    enc_b = sum(len(pages_bytes[i % uniq]) for i in range(n_pages)) + (dictionary.nbytes if dictionary is not None else 0)
     dec_b = sum(int(res[i].out_bytes) + (4 * (int(res[i].out_values) + 1) if off is not None else 0) for i in range(n_pages))
     print(f"{name:34s} {n_pages:5d} pages  {t*1e6:9.1f} us  decoded {dec_b/t/1e9:8.1f} GB/s  algorithmic {(enc_b+dec_b)/t/1e9:8.1f} GB/s  "
           f"frac {(enc_b+dec_b)/t/8e12:.3f}", flush=True)
     batch.close()
+    return t
 
 
 def main():
