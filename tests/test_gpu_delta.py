@@ -120,6 +120,39 @@ def test_large_pages_and_shapes():
     _run(cases, P.KIND.INT32, np.int32, O.delta_decode_int32)
 
 
+def test_block_sizes_that_vary():
+    """Pages whose blocks differ in size from one to the next: min-delta varints of 1..10 bytes,
+    miniblock widths that change inside and between blocks, single odd blocks in steady pages."""
+    P = pkg()
+    rng = np.random.default_rng(77)
+    cases = []
+    n = 40000
+    # varint length jitter: the block minimum straddles a 7-bit boundary
+    for bw in (7, 12, 14, 21, 48, 62):
+        v = np.cumsum(rng.integers(0, 1 << bw, size=n, dtype=np.int64) >> rng.integers(0, 3, size=n))
+        cases.append((f"jitter-bw{bw}", O.delta_encode_int64(v), bw % 16))
+    # widths drawn per stretch of 32 values, so every miniblock has its own
+    widths = rng.integers(0, 40, size=n // 32 + 1)
+    d = np.concatenate([rng.integers(0, 1 << int(w), size=32, dtype=np.int64) for w in widths])[:n]
+    cases.append(("width-per-miniblock", O.delta_encode_int64(np.cumsum(d)), 3))
+    # steady page with a spike every few thousand values
+    d = rng.integers(1000, 1016, size=n, dtype=np.int64)
+    d[rng.integers(0, n, size=12)] = 1 << 40
+    d[rng.integers(0, n, size=12)] = -(1 << 33)
+    cases.append(("spikes", O.delta_encode_int64(np.cumsum(d)), 5))
+    # sign changes: min deltas from -2**62 to 2**62 (ten-byte varints next to one-byte ones)
+    d = rng.integers(-8, 8, size=n, dtype=np.int64)
+    d[::517] = rng.integers(-2**62, 2**62, size=d[::517].size, dtype=np.int64)
+    with np.errstate(over="ignore"):
+        cases.append(("wide-minima", O.delta_encode_int64(np.cumsum(d)), 9))
+    _run(cases, P.KIND.INT64, np.int64, O.delta_decode_int64)
+    cases32 = []
+    for bw in (7, 13, 20, 30):
+        v = np.cumsum(rng.integers(0, 1 << bw, size=n, dtype=np.int64) >> rng.integers(0, 3, size=n)).astype(np.int32)
+        cases32.append((f"jitter32-bw{bw}", O.delta_encode_int32(v), bw % 16))
+    _run(cases32, P.KIND.INT32, np.int32, O.delta_decode_int32)
+
+
 def test_errors_and_truncation():
     P = pkg()
     v = np.cumsum(np.arange(1000, dtype=np.int64) ** 2)
