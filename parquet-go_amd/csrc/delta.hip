@@ -477,11 +477,8 @@ void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict_
 
     const uint32_t total = (uint32_t)sh.ctl.total;          // <= MaxInt32
     const uint32_t vpm = sh.ctl.vpm;
-    const uint32_t nmb = sh.ctl.slot_base;
     const uint32_t block_size = sh.ctl.count;
     const uint32_t vpm_shift = vpm ? 31 - __clz(vpm) : 0;
-    const uint32_t blk_shift = block_size ? 31 - __clz(block_size) : 0;
-    const uint32_t nb_tile = block_size ? TILE >> blk_shift : 1;       // blocks per tile
     const uint32_t slots_tile = vpm ? TILE >> vpm_shift : 1;           // miniblocks per tile
     int stop = sh.ctl.stop;
     int32_t status = sh.ctl.status;
@@ -489,7 +486,6 @@ void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict_
     uint32_t consumed = (uint32_t)sh.ctl.consumed;
     U carry = (U)sh.ctl.first;
     uint32_t done = 0;
-    const uint32_t n_deltas = total > 0 ? total - 1 : 0;
     uint32_t lo = (uint32_t)sh.ctl.lo;   // start of the next tile's bytes
     uint32_t guess = 0, alt = 0;         // wave 0: the block size the walk expects; the last size that differed
     uint32_t tbl_tiles = 0, tbl_next = 0, tbl_got = 0;

@@ -352,7 +352,7 @@ __global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict
 constexpr int ET = 256;
 constexpr uint32_t STAGE_BYTES = RLE_TILE * 4 + 64; // packed bytes of one tile at 32 bits per value, plus slack
 constexpr uint32_t MAX_TILE_RUNS = RLE_TILE + 2;
-constexpr uint32_t RUN_LOOP_MAX = 16;          // tiles with at most this many runs are expanded run by run
+constexpr uint32_t RT_CAP = MAX_TILE_RUNS * 4 / 16; // whole run-table entries the run_start buffer can hold instead
 
 constexpr uint32_t MAX_GROUP = 8;             // steps one expand workgroup may take
 
@@ -361,6 +361,7 @@ struct EShared {
     uint32_t run_start[MAX_TILE_RUNS];
     u32x4 first_run[MAX_GROUP];   // per step: the run that holds its first value ...
     uint32_t first_idx[MAX_GROUP]; // ... and that run's index
+    uint32_t span_lo, span_hi;     // byte range of the packed data being staged
 };
 
 // Number of values the item writes, after the caller's length fix-up
@@ -443,14 +444,64 @@ __device__ inline void expand_tile(EShared& sh, const DevPage& pg, DevResult* re
     // chosen so one store instruction of a wave covers contiguous memory
     constexpr int G = ELEM == 1 ? 8 : (ELEM == 8 ? 2 : 4);
     constexpr int R = 8 / G;
+    const uint32_t mask = bw >= 32 ? 0xffffffffu : ((1u << bw) - 1);
 
-    // ---- values [s0, s0 + sn) of the page, all inside the bit-packed run `run`: packed bytes staged
-    // through LDS with aligned 16-byte loads, every lane cuts its fields out of two LDS dwords ----
-    auto bitpacked_span = [&](const Run& run, uint64_t s0, uint32_t sn) {
-        const uint64_t k0 = s0 - run.out_start;            // first field of the span within the run
+    // ---- the G values v of repetition r, values [s0 + j, s0 + j + G) of the page with j + g < sn:
+    // through the dictionary if there is one, then one vector store where the destination allows ----
+    auto emit = [&](uint64_t s0, uint32_t sn, int r, const uint32_t (&v)[G]) {
+        const uint32_t j = r * (ET * G) + tid * G;
+        if (!FUSED && dense && j + G <= sn) {
+            gptr<uint8_t> p = as_global(pg.dst) + (s0 + j) * ELEM;
+            if (ELEM == 1) {
+                u32x2_a4 w;
+                w.x = v[0] | (v[1 % G] << 8) | (v[2 % G] << 16) | (v[3 % G] << 24);
+                w.y = v[4 % G] | (v[5 % G] << 8) | (v[6 % G] << 16) | (v[7 % G] << 24);
+                if (((uintptr_t)p & 3) == 0) *(gptr<u32x2_a4>)(p) = w;
+                else for (int g = 0; g < 8; g++) p[g] = (uint8_t)v[g % G];
+            } else {
+                u32x4_a4 w;
+                w.x = v[0]; w.y = v[1 % G]; w.z = v[2 % G]; w.w = v[3 % G];
+                *(gptr<u32x4_a4>)(p) = w;
+            }
+        } else if (FUSED && dense && ELEM == 8 && j + G <= sn) {
+            // gather two 8-byte values, store 16 contiguous bytes
+            uint64_t x[2];
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                const uint32_t idx = v[g % G];
+                const bool ok = (uint64_t)idx < pg.dict_len;
+                if (!ok) atomicMin(reinterpret_cast<unsigned long long*>(&res->aux), (unsigned long long)(s0 + j + g));
+                x[g] = ok ? ((gptr<const uint64_t>)(pg.dict))[idx] : 0ull;
+            }
+            u64x2_a8 w;
+            w.x = x[0]; w.y = x[1];
+            *(gptr<u64x2_a8>)(as_global(pg.dst) + (s0 + j) * 8) = w;
+        } else if (FUSED && dense && ELEM == 4 && j + G <= sn) {
+            uint32_t x[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const uint32_t idx = v[g % G];
+                const bool ok = (uint64_t)idx < pg.dict_len;
+                if (!ok) atomicMin(reinterpret_cast<unsigned long long*>(&res->aux), (unsigned long long)(s0 + j + g));
+                x[g] = ok ? ((gptr<const uint32_t>)(pg.dict))[idx] : 0u;
+            }
+            u32x4_a4 w;
+            w.x = x[0]; w.y = x[1]; w.z = x[2]; w.w = x[3];
+            *(gptr<u32x4_a4>)(as_global(pg.dst) + (s0 + j) * 4) = w;
+        } else {
+#pragma unroll
+            for (int g = 0; g < G; g++)
+                if (j + g < sn) store_value<ELEM, FUSED>(pg, res, s0 + j + g, v[g], stride);
+        }
+    };
+
+    if (single && (first.count_kind & 1)) {
+        // ---- the whole tile lies inside one bit-packed run: packed bytes staged through LDS with
+        // aligned 16-byte loads, every lane cuts its fields out of two LDS dwords ----
+        const uint64_t k0 = t0 - first.out_start;            // first field of the tile within the run
         const uint64_t bit0 = k0 * bw;
-        const uint64_t byte0 = (uint64_t)run.in_off + (bit0 >> 3);
-        const uint64_t byte1 = (uint64_t)run.in_off + ((bit0 + (uint64_t)sn * bw + 7) >> 3);
+        const uint64_t byte0 = (uint64_t)first.in_off + (bit0 >> 3);
+        const uint64_t byte1 = (uint64_t)first.in_off + ((bit0 + (uint64_t)n_stream * bw + 7) >> 3);
         const uint64_t mis = (uintptr_t)(src + byte0) & 15;
         gptr<const uint8_t> abase = src + byte0 - mis;
         const uint64_t span = mis + (byte1 - byte0);        // bytes to stage, from the aligned base
@@ -460,125 +511,128 @@ __device__ inline void expand_tile(EShared& sh, const DevPage& pg, DevResult* re
         }
         __syncthreads();
         const uint32_t bitbase = (uint32_t)(mis * 8 + (bit0 & 7));
-        const uint32_t mask = bw >= 32 ? 0xffffffffu : ((1u << bw) - 1);
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const uint32_t j = r * (ET * G) + tid * G;
             uint32_t v[G];
 #pragma unroll
             for (int g = 0; g < G; g++) {
-                uint32_t b = bitbase + (j + g) * bw;
-                uint32_t k = b >> 5, s = b & 31;
-                uint64_t w01 = (uint64_t)sh.stage[k] | ((uint64_t)sh.stage[k + 1] << 32);
+                const uint32_t b = bitbase + (j + g) * bw;
+                const uint32_t k = b >> 5, s = b & 31;
+                const uint64_t w01 = (uint64_t)sh.stage[k] | ((uint64_t)sh.stage[k + 1] << 32);
                 v[g] = (uint32_t)(w01 >> s) & mask;
             }
-            if (!FUSED && dense && j + G <= sn) {
-                gptr<uint8_t> p = as_global(pg.dst) + (s0 + j) * ELEM;
-                if (ELEM == 1) {
-                    u32x2_a4 w;
-                    w.x = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
-                    w.y = v[4 % G] | (v[5 % G] << 8) | (v[6 % G] << 16) | (v[7 % G] << 24);
-                    if (((uintptr_t)p & 3) == 0) *(gptr<u32x2_a4>)(p) = w;
-                    else for (int g = 0; g < 8; g++) p[g] = (uint8_t)v[g % G];
-                } else {
-                    u32x4_a4 w;
-                    w.x = v[0]; w.y = v[1 % G]; w.z = v[2 % G]; w.w = v[3 % G];
-                    *(gptr<u32x4_a4>)(p) = w;
-                }
-            } else if (FUSED && dense && ELEM == 8 && j + G <= sn) {
-                // gather two 8-byte values, store 16 contiguous bytes
-                uint64_t x[2];
-#pragma unroll
-                for (int g = 0; g < 2; g++) {
-                    const uint32_t idx = v[g % G];
-                    const bool ok = (uint64_t)idx < pg.dict_len;
-                    if (!ok) atomicMin(reinterpret_cast<unsigned long long*>(&res->aux), (unsigned long long)(s0 + j + g));
-                    x[g] = ok ? ((gptr<const uint64_t>)(pg.dict))[idx] : 0ull;
-                }
-                u64x2_a8 w;
-                w.x = x[0]; w.y = x[1];
-                *(gptr<u64x2_a8>)(as_global(pg.dst) + (s0 + j) * 8) = w;
-            } else if (FUSED && dense && ELEM == 4 && j + G <= sn) {
-                uint32_t x[4];
-#pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const uint32_t idx = v[g % G];
-                    const bool ok = (uint64_t)idx < pg.dict_len;
-                    if (!ok) atomicMin(reinterpret_cast<unsigned long long*>(&res->aux), (unsigned long long)(s0 + j + g));
-                    x[g] = ok ? ((gptr<const uint32_t>)(pg.dict))[idx] : 0u;
-                }
-                u32x4_a4 w;
-                w.x = x[0]; w.y = x[1]; w.z = x[2]; w.w = x[3];
-                *(gptr<u32x4_a4>)(as_global(pg.dst) + (s0 + j) * 4) = w;
-            } else {
-#pragma unroll
-                for (int g = 0; g < G; g++)
-                    if (j + g < sn) store_value<ELEM, FUSED>(pg, res, s0 + j + g, v[g], stride);
-            }
+            emit(t0, n_stream, r, v);
         }
-    };
-
-    if (single && (first.count_kind & 1)) {
-        bitpacked_span(first, t0, n_stream);
     } else if (single) {
         // ---- the whole tile lies inside one repeated run ----
         if (!FUSED && dense && (ELEM == 1 || ELEM == 4)) fill_dense<(ELEM == 1 ? 1 : 4)>(pg, t0, t0 + n_stream, first.value);
         else for (uint32_t j = tid; j < n_stream; j += ET) store_value<ELEM, FUSED>(pg, res, t0 + j, first.value, stride);
     } else if (n_stream > 0) {
-        // ---- mixed tile: stage the out_start of every run that intersects it ----
-        uint64_t avail = n_runs - r0;
-        uint32_t nr = avail < MAX_TILE_RUNS ? (uint32_t)avail : MAX_TILE_RUNS;
-        for (uint32_t k = tid; k < nr; k += ET) sh.run_start[k] = runs[r0 + k].out_start;
+        // ---- mixed tile: the run-table entries that meet it and the packed bytes of its bit-packed
+        // runs are copied to LDS; every lane then finds the run of its values by bisection there ----
+        const uint64_t avail = n_runs - r0;
+        const uint32_t nr = avail < RT_CAP ? (uint32_t)avail : RT_CAP;
+        u32x4* tab = reinterpret_cast<u32x4*>(sh.run_start);
+        for (uint32_t k = tid; k < nr; k += ET) tab[k] = *(gptr<const u32x4>)(runs + r0 + k);
+        if (tid == 0) { sh.span_lo = 0xffffffffu; sh.span_hi = 0; }
         __syncthreads();
-        // runs that start inside the tile (the first one starts at or before t0)
-        uint32_t in_tile;
+        uint32_t in_tile; // staged runs that start before the end of the tile (the first one starts at or before t0)
         {
-            uint32_t lo = 0, hi = nr; // last staged run with out_start < t0 + n_stream
+            uint32_t lo = 0, hi = nr;
             while (hi - lo > 1) {
                 const uint32_t mid = (lo + hi) >> 1;
-                if ((uint64_t)sh.run_start[mid] < t0 + n_stream) lo = mid; else hi = mid;
+                if ((uint64_t)tab[mid].x < t0 + n_stream) lo = mid; else hi = mid;
             }
             in_tile = lo + 1;
         }
-        if (in_tile <= RUN_LOOP_MAX) {
-            // ---- a few runs: take them one after the other, each with the whole workgroup ----
-            for (uint32_t k = 0; k < in_tile; k++) {
-                const Run rr = load_run(runs, r0 + k);
-                const uint64_t rb = rr.out_start, re = rb + (rr.count_kind >> 1);
-                const uint64_t s0 = rb > t0 ? rb : t0;
-                const uint64_t s1 = re < t0 + n_stream ? re : t0 + n_stream;
-                if (s1 <= s0) continue;
-                if (rr.count_kind & 1) {
-                    __syncthreads(); // the staging buffer is reused from span to span
-                    bitpacked_span(rr, s0, (uint32_t)(s1 - s0));
-                } else {
-                    if (!FUSED && dense && (ELEM == 1 || ELEM == 4)) fill_dense<(ELEM == 1 ? 1 : 4)>(pg, s0, s1, rr.value);
-                    else for (uint64_t q = s0 + tid; q < s1; q += ET) store_value<ELEM, FUSED>(pg, res, q, rr.value, stride);
+        const u32x4 last = tab[in_tile - 1];
+        bool in_lds = (uint64_t)last.x + (last.w >> 1) >= t0 + n_stream; // else the tile goes on past the staged entries
+        for (uint32_t k = tid; k < in_tile; k += ET) {
+            const u32x4 e = tab[k];
+            if (e.w & 1) {
+                const uint64_t rb = e.x, re = rb + (e.w >> 1);
+                const uint64_t s0 = rb > t0 ? rb : t0, s1 = re < t0 + n_stream ? re : t0 + n_stream;
+                if (s1 > s0) {
+                    atomicMin(&sh.span_lo, e.y + (uint32_t)(((s0 - rb) * bw) >> 3));
+                    atomicMax(&sh.span_hi, e.y + (uint32_t)(((s1 - rb) * bw + 7) >> 3));
                 }
             }
-        } else
-        for (uint32_t j = tid; j < n_stream; j += ET) {
-            const uint64_t pos = t0 + j;
-            uint32_t lo = 0, hi = nr; // last staged run with out_start <= pos
-            while (hi - lo > 1) {
-                uint32_t mid = (lo + hi) >> 1;
-                if ((uint64_t)sh.run_start[mid] <= pos) lo = mid; else hi = mid;
+        }
+        __syncthreads();
+        const uint32_t b_lo = sh.span_lo, b_hi = sh.span_hi;
+        int64_t base = 0; // src offset of stage byte 0: up to 15 bytes before the first packed byte, so the loads are aligned
+        if (b_hi > b_lo && b_lo != 0xffffffffu) {
+            base = (int64_t)b_lo - (int64_t)((uintptr_t)(pg.src + b_lo) & 15);
+            const uint32_t span = (uint32_t)((int64_t)b_hi - base);
+            if (span > STAGE_BYTES - 64) in_lds = false;
+            else if (in_lds)
+                for (uint32_t c = tid * 16; c < span; c += ET * 16)
+                    *reinterpret_cast<u32x4*>(&sh.stage[c >> 2]) = *(gptr<const u32x4>)(src + base + c);
+        }
+        __syncthreads();
+        if (in_lds) {
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const uint32_t j = r * (ET * G) + tid * G;
+                uint32_t v[G];
+#pragma unroll
+                for (int g = 0; g < G; g++) v[g] = 0;
+                if (j < n_stream) {
+                    const uint64_t pos = t0 + j;
+                    uint32_t lo = 0, hi = in_tile; // last staged run with out_start <= pos
+                    while (hi - lo > 1) {
+                        const uint32_t mid = (lo + hi) >> 1;
+                        if ((uint64_t)tab[mid].x <= pos) lo = mid; else hi = mid;
+                    }
+                    u32x4 e = tab[lo];
+#pragma unroll
+                    for (int g = 0; g < G; g++) {
+                        const uint64_t q = pos + g;
+                        if (j + g >= n_stream) break; // past the end of the stream: stays zero
+                        if (q >= (uint64_t)e.x + (e.w >> 1) && lo + 1 < in_tile) e = tab[++lo]; // every run holds at least one value
+                        if (e.w & 1) {
+                            const uint64_t bits = (q - e.x) * bw;
+                            const uint32_t b = (uint32_t)((int64_t)e.y + (int64_t)(bits >> 3) - base) * 8 + (uint32_t)(bits & 7);
+                            const uint32_t k = b >> 5;
+                            const uint64_t w01 = (uint64_t)sh.stage[k] | ((uint64_t)sh.stage[k + 1] << 32);
+                            v[g] = (uint32_t)(w01 >> (b & 31)) & mask;
+                        } else {
+                            v[g] = e.z;
+                        }
+                    }
+                }
+                emit(t0, n_stream, r, v);
             }
-            const Run rr = load_run(runs, r0 + lo);
-            uint32_t v;
-            if (rr.count_kind & 1) {
-                // bytes touched all belong to this run, which the index kernel bounds-checked
-                uint64_t bit = (pos - rr.out_start) * bw;
-                gptr<const uint8_t> q = src + rr.in_off + (bit >> 3);
-                uint32_t s = (uint32_t)(bit & 7);
-                uint32_t nb = (s + bw + 7) >> 3;
-                uint64_t acc = 0;
-                for (uint32_t b = 0; b < nb; b++) acc |= (uint64_t)q[b] << (8 * b);
-                v = (uint32_t)(acc >> s) & (bw >= 32 ? 0xffffffffu : ((1u << bw) - 1));
-            } else {
-                v = rr.value;
+        } else {
+            // ---- more runs or packed bytes than the LDS buffers hold: the out_start of every run,
+            // a bisection per value, entries and bytes read from memory ----
+            const uint32_t nr2 = avail < MAX_TILE_RUNS ? (uint32_t)avail : MAX_TILE_RUNS;
+            for (uint32_t k = tid; k < nr2; k += ET) sh.run_start[k] = runs[r0 + k].out_start;
+            __syncthreads();
+            for (uint32_t j = tid; j < n_stream; j += ET) {
+                const uint64_t pos = t0 + j;
+                uint32_t lo = 0, hi = nr2; // last staged run with out_start <= pos
+                while (hi - lo > 1) {
+                    uint32_t mid = (lo + hi) >> 1;
+                    if ((uint64_t)sh.run_start[mid] <= pos) lo = mid; else hi = mid;
+                }
+                const Run rr = load_run(runs, r0 + lo);
+                uint32_t v;
+                if (rr.count_kind & 1) {
+                    // bytes touched all belong to this run, which the index kernel bounds-checked
+                    uint64_t bit = (pos - rr.out_start) * bw;
+                    gptr<const uint8_t> q = src + rr.in_off + (bit >> 3);
+                    uint32_t s = (uint32_t)(bit & 7);
+                    uint32_t nb = (s + bw + 7) >> 3;
+                    uint64_t acc = 0;
+                    for (uint32_t b = 0; b < nb; b++) acc |= (uint64_t)q[b] << (8 * b);
+                    v = (uint32_t)(acc >> s) & mask;
+                } else {
+                    v = rr.value;
+                }
+                store_value<ELEM, FUSED>(pg, res, pos, v, stride);
             }
-            store_value<ELEM, FUSED>(pg, res, pos, v, stride);
         }
     }
     // zero-extended tail of a dictionary page
@@ -592,7 +646,6 @@ __device__ inline void expand_tile(EShared& sh, const DevPage& pg, DevResult* re
 // and the runs are then expanded one after the other out of LDS: three dependent round trips
 // to memory per workgroup instead of three per run.  Returns false when the group does not
 // fit these buffers; the caller then takes it step by step.
-constexpr uint32_t RT_CAP = MAX_TILE_RUNS * 4 / 16; // run-table entries the run_start buffer can hold instead
 constexpr uint32_t GROUP_SHORT_RUN = 1024;          // runs of at most this many values are expanded by one wavefront
 constexpr uint32_t GROUP_STAGE_PAD = 16;           // bytes left free before the staged packed data
 
@@ -608,7 +661,7 @@ __device__ inline bool expand_group_bytes(EShared& sh, const DevPage& pg, uint64
     const uint64_t r_first = n_runs > 1 ? as_global((const uint32_t*)pg.tile_run)[G0 / RLE_TILE] : 0;
     const uint32_t K = n_runs - r_first < RT_CAP ? (uint32_t)(n_runs - r_first) : RT_CAP;
     for (uint32_t k = tid; k < K; k += ET) tab[k] = *(gptr<const u32x4>)(runs + r_first + k);
-    if (tid == 0) { sh.first_idx[0] = 0xffffffffu; sh.first_idx[1] = 0; } // byte range of the packed data: lo, hi
+    if (tid == 0) { sh.span_lo = 0xffffffffu; sh.span_hi = 0; }
     __syncthreads();
     // runs that start before the end of the group
     uint32_t nr;
@@ -630,13 +683,13 @@ __device__ inline bool expand_group_bytes(EShared& sh, const DevPage& pg, uint64
             const uint64_t rb = r.x, re = rb + (r.w >> 1);
             const uint64_t s0 = rb > G0 ? rb : G0, s1 = re < G0 + GS ? re : G0 + GS;
             if (s1 > s0) {
-                atomicMin(&sh.first_idx[0], r.y + (uint32_t)(((s0 - rb) * bw) >> 3));
-                atomicMax(&sh.first_idx[1], r.y + (uint32_t)(((s1 - rb) * bw + 7) >> 3));
+                atomicMin(&sh.span_lo, r.y + (uint32_t)(((s0 - rb) * bw) >> 3));
+                atomicMax(&sh.span_hi, r.y + (uint32_t)(((s1 - rb) * bw + 7) >> 3));
             }
         }
     }
     __syncthreads();
-    const uint32_t b_lo = sh.first_idx[0], b_hi = sh.first_idx[1];
+    const uint32_t b_lo = sh.span_lo, b_hi = sh.span_hi;
     int64_t base = 0; // src offset of stage byte 0: up to 15 bytes before the first packed byte, so the loads are aligned
     if (b_hi > b_lo && b_lo != 0xffffffffu) {
         base = (int64_t)b_lo - (int64_t)((uintptr_t)(pg.src + b_lo) & 15);
