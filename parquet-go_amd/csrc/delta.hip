@@ -477,7 +477,6 @@ void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict_
 
     const uint32_t total = (uint32_t)sh.ctl.total;          // <= MaxInt32
     const uint32_t vpm = sh.ctl.vpm;
-    const uint32_t block_size = sh.ctl.count;
     const uint32_t vpm_shift = vpm ? 31 - __clz(vpm) : 0;
     const uint32_t slots_tile = vpm ? TILE >> vpm_shift : 1;           // miniblocks per tile
     int stop = sh.ctl.stop;
