@@ -46,6 +46,7 @@ struct pqd_batch {
     uint32_t* d_rle_tile_item[4] = {nullptr, nullptr, nullptr, nullptr}; // grid tile -> position in the family list (null: the kernel searches the prefix)
     uint64_t rle_tiles[4] = {0, 0, 0, 0};
     uint64_t rle_steps = 0;
+    RleChunks ck; // long RLE pages indexed chunk by chunk
     // generic tile grids for the element-parallel families
     uint64_t max_src[16] = {0}; // longest src of each family, sizes the tile grids
     std::vector<DevResult> h_results;
@@ -82,6 +83,8 @@ int32_t elem_width_of(int32_t kind, int32_t bit_width) {
 // encoding.NotSupported would answer (encoding/notsupported.go:163-197).
 // The RLE hybrid families share the index kernel; each has an expand kernel and a tile grid of its own.
 constexpr int RLE_GRIDS = 4;
+constexpr size_t RLE_CHUNKED_MAX_PAGES = 512;      // batches with more RLE pages than this index them one wavefront each
+constexpr uint64_t RLE_CHUNKED_MIN_BYTES = 16384;   // shorter pages are not worth cutting up
 constexpr int32_t RLE_FAMILY[RLE_GRIDS] = {FAM_RLE, FAM_RLE_BYTES, FAM_RLE_DICT8, FAM_RLE_DICT4};
 inline int rle_grid(int32_t family) {
     for (int g = 0; g < RLE_GRIDS; g++) if (RLE_FAMILY[g] == family) return g;
@@ -150,6 +153,7 @@ DevPage make_item(const pqd_page& p, int32_t family) {
     d.family = family;
     d.chain = -1;
     d.fused = 0;
+    d.ck_index = -1;
     return d;
 }
 
@@ -316,6 +320,49 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
         if (b->rle_tiles[g] > 0x7fffffffull) { delete b; return PQD_ERR_INVALID_ARGUMENT; }
     }
 
+    // ---- long RLE pages of a batch with few of them: indexed chunk by chunk, by many workgroups each ----
+    // (a batch with many RLE pages keeps the chip busy with one wavefront per page; a page that is
+    // nearly as long as its values bit-packed in one run has few run headers and is quickest that way too)
+    std::vector<uint32_t> ck_items, ck_prefix, ck_page, ck_chunk;
+    {
+        size_t n_rle = 0;
+        for (int g = 0; g < RLE_GRIDS; g++) n_rle += b->fam[RLE_FAMILY[g]].items.size();
+        const uint64_t chunk = rle_chunk_bytes();
+        uint64_t n_chunks = 0;
+        std::vector<uint32_t> per_page;
+        if (n_rle <= RLE_CHUNKED_MAX_PAGES) {
+            for (uint32_t k = 0; k < b->items.size(); k++) {
+                DevPage& d = b->items[k];
+                if (!is_rle(d.family) || d.src_len < RLE_CHUNKED_MIN_BYTES || d.src_len > 0xfff00000ull) continue;
+                if (d.num_values >= 0) {
+                    // widest the values can be: the declared width, or what the dictionary's size allows
+                    uint64_t width = d.bit_width > 0 ? (uint64_t)d.bit_width : 32;
+                    if (d.fused && d.dict_len > 0) {
+                        width = 0;
+                        for (uint64_t m = d.dict_len - 1; m; m >>= 1) width++;
+                    } else if (d.kind == PQD_KIND_BOOLEAN) {
+                        width = 1;
+                    }
+                    const uint64_t packed = ((uint64_t)d.num_values * width + 7) / 8;
+                    if (d.src_len * 10 >= packed * 9) continue;
+                }
+                const uint64_t span = (reinterpret_cast<uintptr_t>(d.src) & 15) + d.src_len;
+                const uint64_t n = (span + chunk - 1) / chunk;
+                if (n_chunks + n > 0x7fffffffull) break;
+                d.ck_index = (int32_t)ck_items.size();
+                ck_items.push_back(k);
+                ck_prefix.push_back((uint32_t)n_chunks);
+                per_page.push_back((uint32_t)n);
+                n_chunks += n;
+            }
+        }
+        ck_prefix.push_back((uint32_t)n_chunks);
+        for (uint32_t c = 0; ck_page.size() < n_chunks; c++)
+            for (uint32_t k = 0; k < per_page.size(); k++)
+                if (c < per_page[k]) { ck_page.push_back(k); ck_chunk.push_back(c); }
+        b->ck.n_chunks = (uint32_t)n_chunks;
+    }
+
     // ---- carve one arena ----
     const size_t n_items = b->items.size();
     size_t off = 0;
@@ -332,6 +379,21 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
         o_rle_tile_item[g] = carve(with_tile_item[g] ? b->rle_tiles[g] * sizeof(uint32_t) : 0);
     }
     const size_t o_rle_tile_run = carve(b->rle_steps * sizeof(uint32_t));
+    const size_t nck = b->ck.n_chunks, npk = ck_items.size();
+    const size_t o_ck_items = carve(npk * sizeof(uint32_t));
+    const size_t o_ck_prefix = carve(ck_prefix.size() * sizeof(uint32_t));
+    const size_t o_ck_page = carve(nck * sizeof(uint32_t));
+    const size_t o_ck_chunk = carve(nck * sizeof(uint32_t));
+    const size_t o_ck_entry = carve(nck * sizeof(uint32_t));
+    const size_t o_ck_exit = carve(nck * sizeof(uint32_t));
+    const size_t o_ck_links = carve(nck * (size_t)rle_chunk_bytes() * sizeof(uint16_t));
+    const size_t o_ck_state = carve(0); // the block cleared before every launch starts here
+    const size_t o_ck_counters = carve(2 * sizeof(uint32_t));
+    const size_t o_ck_flag = carve(npk * sizeof(uint32_t));
+    const size_t o_ck_pos = carve(npk * sizeof(uint32_t));
+    const size_t o_ck_runs = carve(nck * sizeof(unsigned long long));
+    const size_t o_ck_vals = carve(nck * sizeof(unsigned long long));
+    const size_t o_ck_state_end = carve(0);
     const size_t o_runs = carve(runs_entries * sizeof(Run));
     const size_t o_lengths = carve(lengths_entries * sizeof(int32_t));
     b->arena_bytes = std::max<size_t>(off, 256);
@@ -343,6 +405,20 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
         b->d_rle_tile_prefix[g] = reinterpret_cast<uint64_t*>(a + o_rle_prefix[g]);
         b->d_rle_tile_item[g] = with_tile_item[g] ? reinterpret_cast<uint32_t*>(a + o_rle_tile_item[g]) : nullptr;
     }
+    b->ck.items = reinterpret_cast<uint32_t*>(a + o_ck_items);
+    b->ck.prefix = reinterpret_cast<uint32_t*>(a + o_ck_prefix);
+    b->ck.page = reinterpret_cast<uint32_t*>(a + o_ck_page);
+    b->ck.chunk = reinterpret_cast<uint32_t*>(a + o_ck_chunk);
+    b->ck.entry = reinterpret_cast<uint32_t*>(a + o_ck_entry);
+    b->ck.exit = reinterpret_cast<uint32_t*>(a + o_ck_exit);
+    b->ck.links = reinterpret_cast<uint16_t*>(a + o_ck_links);
+    b->ck.page_pos = reinterpret_cast<uint32_t*>(a + o_ck_pos);
+    b->ck.state = a + o_ck_state;
+    b->ck.state_bytes = o_ck_state_end - o_ck_state;
+    b->ck.counters = reinterpret_cast<uint32_t*>(a + o_ck_counters);
+    b->ck.pk_flag = reinterpret_cast<uint32_t*>(a + o_ck_flag);
+    b->ck.runs = reinterpret_cast<unsigned long long*>(a + o_ck_runs);
+    b->ck.vals = reinterpret_cast<unsigned long long*>(a + o_ck_vals);
     Run* runs = reinterpret_cast<Run*>(a + o_runs);
     int32_t* lengths = reinterpret_cast<int32_t*>(a + o_lengths);
     for (DevPage& d : b->items) {
@@ -384,6 +460,12 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
                                         hipMemcpyHostToDevice));
         }
     }
+    if (nck > 0) {
+        ok = ok && hip_ok(hipMemcpy(a + o_ck_items, ck_items.data(), npk * sizeof(uint32_t), hipMemcpyHostToDevice));
+        ok = ok && hip_ok(hipMemcpy(a + o_ck_prefix, ck_prefix.data(), ck_prefix.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        ok = ok && hip_ok(hipMemcpy(a + o_ck_page, ck_page.data(), nck * sizeof(uint32_t), hipMemcpyHostToDevice));
+        ok = ok && hip_ok(hipMemcpy(a + o_ck_chunk, ck_chunk.data(), nck * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     if (!ok) { (void)hipFree(b->arena); delete b; return PQD_ERR_DEVICE; }
     b->h_results.resize(n_items);
     *out = b;
@@ -396,9 +478,10 @@ int pqd_batch_launch(pqd_batch* b, void* hip_stream) {
     launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA32].dev, (uint32_t)b->fam[FAM_DELTA32].items.size(), false, s);
     launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA32_CHAINED].dev, (uint32_t)b->fam[FAM_DELTA32_CHAINED].items.size(), false, s);
     launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA64].dev, (uint32_t)b->fam[FAM_DELTA64].items.size(), true, s);
+    launch_rle_chunked(b->d_items, b->d_results, b->ck, s);
     for (int g = 0; g < RLE_GRIDS; g++) {
         const FamilyList& f = b->fam[RLE_FAMILY[g]];
-        launch_rle_index(b->d_items, b->d_results, f.dev, (uint32_t)f.items.size(), s);
+        launch_rle_index(b->d_items, b->d_results, f.dev, (uint32_t)f.items.size(), b->ck.pk_flag, s);
     }
     for (int g = 0; g < RLE_GRIDS; g++) {
         const FamilyList& f = b->fam[RLE_FAMILY[g]];

@@ -57,6 +57,7 @@ struct DevPage {
     int32_t family;       // kernel family
     int32_t chain;        // index of the item whose `consumed` gives this item's src offset, or -1
     int32_t fused;        // RLE family: indices go straight through the dictionary gather
+    int32_t ck_index;     // RLE family: position in the list of pages indexed chunk by chunk, or -1
 };
 
 struct DevResult {
@@ -148,8 +149,33 @@ __device__ inline void set_status(DevResult* r, int32_t status, int64_t arg) {
 // Kernel launchers (defined in the .hip files).
 void launch_delta(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, bool is64,
                   hipStream_t stream);
-void launch_rle_index(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
+void launch_rle_index(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, const uint32_t* pk_flag,
                       hipStream_t stream);
+
+// Device arrays of the chunked RLE index (long pages cut into chunks, one workgroup each).
+// Workgroups take (page, chunk) pairs in the order of the `page` / `chunk` lists, which go
+// round the pages chunk by chunk, so that all pages advance together; the per-chunk arrays
+// are indexed by prefix[page] + chunk.
+struct RleChunks {
+    uint32_t n_chunks = 0;
+    const uint32_t* items = nullptr;   // per chunked page: its index in the batch's item array
+    const uint32_t* prefix = nullptr;  // per chunked page: its first place in the per-chunk arrays
+    const uint32_t* page = nullptr;    // per work item: its page in the list of chunked pages
+    const uint32_t* chunk = nullptr;   // per work item: its chunk of that page
+    uint32_t* entry = nullptr;         // per chunk: where the chain of run headers enters it
+    uint32_t* exit = nullptr;          // per chunk: where it leaves it
+    uint16_t* links = nullptr;         // per chunk and byte: where the header after one starting there starts
+    // cleared before every launch, one block of memory:
+    void* state = nullptr;
+    size_t state_bytes = 0;
+    uint32_t* counters = nullptr;      // two: the order in which the workgroups of each kernel start
+    uint32_t* pk_flag = nullptr;       // per chunked page: nonzero = left to the one-wavefront kernel
+    uint32_t* page_pos = nullptr;      // per chunked page: how far the chain of run headers is known
+    unsigned long long* runs = nullptr; // per chunk: ready bit | run-table entries it adds
+    unsigned long long* vals = nullptr; // per chunk: ready bit | values it adds
+};
+uint32_t rle_chunk_bytes();
+void launch_rle_chunked(const DevPage* pages, DevResult* results, const RleChunks& c, hipStream_t stream);
 void launch_rle_expand(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
                        const uint64_t* tile_prefix, const uint32_t* tile_item, uint64_t n_tiles, int32_t family, hipStream_t stream);
 

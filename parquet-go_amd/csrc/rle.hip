@@ -59,13 +59,14 @@ struct ICtl {
     int32_t done;
 };
 
+template <uint32_t MASK = IRING_MASK>
 __device__ inline int iring_uvarint(const uint8_t* ring8, uint64_t pos, uint64_t end, uint64_t* out) {
     uint64_t x = 0;
     unsigned s = 0;
     for (int i = 0;; i++) {
         if (pos + i >= end) { *out = 0; return 0; }
         if (i == 10) return -(i + 1);
-        uint32_t b = ring8[(pos + i) & IRING_MASK];
+        uint32_t b = ring8[(pos + i) & MASK];
         if (b < 0x80) {
             if (i == 9 && b > 1) return -(i + 1);
             *out = x | ((uint64_t)b << s);
@@ -90,6 +91,7 @@ struct RunHeader {
     bool slow;
 };
 
+template <uint32_t MASK = IRING_MASK>
 __device__ inline RunHeader parse_run(const uint32_t* ring, uint64_t p, uint64_t end, uint64_t mis, uint64_t start, int32_t mode,
                                       uint32_t bw, bool registers_only) {
     const uint8_t* ring8 = reinterpret_cast<const uint8_t*>(ring);
@@ -100,8 +102,8 @@ __device__ inline RunHeader parse_run(const uint32_t* ring, uint64_t p, uint64_t
     uint64_t after = 0; // the bytes that follow the header, when it was read from registers
     bool have_after = false;
     if (end - p >= 12) {
-        const uint32_t d = ((uint32_t)p & IRING_MASK) >> 2, sh = ((uint32_t)p & 3) * 8;
-        const uint32_t w0 = ring[d], w1 = ring[(d + 1) & (IRING_BYTES / 4 - 1)], w2 = ring[(d + 2) & (IRING_BYTES / 4 - 1)];
+        const uint32_t d = ((uint32_t)p & MASK) >> 2, sh = ((uint32_t)p & 3) * 8;
+        const uint32_t w0 = ring[d], w1 = ring[(d + 1) & (MASK >> 2)], w2 = ring[(d + 2) & (MASK >> 2)];
         const uint32_t a0 = __builtin_amdgcn_alignbit(w1, w0, sh), a1 = __builtin_amdgcn_alignbit(w2, w1, sh);
         // Go's binary.Uvarint on up to four bytes
         if (!(a0 & 0x80)) { u = a0 & 0x7f; k = 1; }
@@ -109,13 +111,13 @@ __device__ inline RunHeader parse_run(const uint32_t* ring, uint64_t p, uint64_t
         else if (!(a0 & 0x800000)) { u = (a0 & 0x7f) | ((a0 >> 1) & 0x3f80) | ((a0 >> 2) & 0x1fc000); k = 3; }
         else if (!(a0 & 0x80000000u)) { u = (a0 & 0x7f) | ((a0 >> 1) & 0x3f80) | ((a0 >> 2) & 0x1fc000) | ((a0 >> 3) & 0xfe00000); k = 4; }
         else if (registers_only) { h.slow = true; return h; }
-        else k = iring_uvarint(ring8, q, end, &u);
+        else k = iring_uvarint<MASK>(ring8, q, end, &u);
         if (k >= 1 && k <= 4) { after = (((uint64_t)a1 << 32) | a0) >> (8 * k); have_after = true; }
     } else if (registers_only) {
         h.slow = true;
         return h;
     } else {
-        k = iring_uvarint(ring8, q, end, &u);
+        k = iring_uvarint<MASK>(ring8, q, end, &u);
     }
     if (k == 0) { h.err = PQD_ERR_UNEXPECTED_EOF; h.err_arg = PQD_EOF_RUN_HEADER; return h; }
     if (k < 0) { h.err = PQD_ERR_VARINT_OVERFLOW; h.err_arg = (int64_t)(p - mis - start); return h; }
@@ -131,7 +133,7 @@ __device__ inline RunHeader parse_run(const uint32_t* ring, uint64_t p, uint64_t
         if (nbytes > end - q) { h.err = PQD_ERR_UNEXPECTED_EOF; h.err_arg = PQD_EOF_BITPACKED_RUN; h.nvals = 0; }
         else { h.kind = 1; h.in_off = (uint32_t)(q - mis); q += nbytes; }
     } else if (mode == MODE_BOOL) {
-        if (q < end) { h.value = have_after ? (uint32_t)after & 0xff : ring8[q & IRING_MASK]; q++; }
+        if (q < end) { h.value = have_after ? (uint32_t)after & 0xff : ring8[q & MASK]; q++; }
         h.nvals = (count + 7) / 8; // bytes of output
         h.kind = 0;
     } else {
@@ -139,7 +141,7 @@ __device__ inline RunHeader parse_run(const uint32_t* ring, uint64_t p, uint64_t
         if (vb > end - q) { h.err = PQD_ERR_UNEXPECTED_EOF; h.err_arg = PQD_EOF_RLE_VALUE; }
         else {
             if (have_after) h.value = vb == 0 ? 0u : (uint32_t)after & (vb >= 4 ? 0xffffffffu : ((1u << (8 * vb)) - 1));
-            else for (uint32_t b = 0; b < vb; b++) h.value |= (uint32_t)ring8[(q + b) & IRING_MASK] << (8 * b);
+            else for (uint32_t b = 0; b < vb; b++) h.value |= (uint32_t)ring8[(q + b) & MASK] << (8 * b);
             q += vb;
             h.nvals = count;
             h.kind = 0;
@@ -174,14 +176,18 @@ __device__ inline void publish_steps(gptr<uint32_t> tile_run, uint32_t n_steps, 
     }
 }
 
-__global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
-                                                      const uint32_t* __restrict__ items) {
-    __shared__ uint32_t ring[IRING_BYTES / 4];
-    __shared__ ICtl ctl;
-    const uint32_t item = items[blockIdx.x];
-    const DevPage& pg = pages[item];
-    DevResult* res = &results[item];
-    const uint32_t tid = threadIdx.x;
+// What the stream of a page is, before any run header: where it starts, how long it is, the
+// decoding mode and bit width, or the error its framing already holds.
+struct PageSetup {
+    uint64_t src_len;  // bytes of the page that belong to the stream (from offset 0: framing included)
+    uint64_t start;    // offset of the first run header
+    int64_t arg;
+    int32_t mode;
+    int32_t status;
+    uint32_t bw;
+};
+
+__device__ inline PageSetup page_setup(const DevPage& pg) {
     gptr<const uint8_t> src = as_global(pg.src);
     uint64_t src_len = pg.src_len;
     int32_t mode = pg.kind == PQD_KIND_LEVELS ? MODE_LEVELS : (pg.kind == PQD_KIND_BOOLEAN ? MODE_BOOL : MODE_INT32);
@@ -211,6 +217,26 @@ __global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict
     }
     if (status0 != PQD_OK) src_len = 0;
 
+    PageSetup ps;
+    ps.src_len = src_len; ps.start = start; ps.arg = arg0; ps.mode = mode; ps.status = status0; ps.bw = bw;
+    return ps;
+}
+
+__global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                      const uint32_t* __restrict__ items, const uint32_t* pk_flag) {
+    __shared__ uint32_t ring[IRING_BYTES / 4];
+    __shared__ ICtl ctl;
+    const uint32_t item = items[blockIdx.x];
+    const DevPage& pg = pages[item];
+    if (pg.ck_index >= 0 && pk_flag[pg.ck_index] == 0) return; // indexed by the chunked kernels
+    DevResult* res = &results[item];
+    const uint32_t tid = threadIdx.x;
+    gptr<const uint8_t> src = as_global(pg.src);
+    const PageSetup ps = page_setup(pg);
+    const uint64_t src_len = ps.src_len, start = ps.start;
+    const int32_t mode = ps.mode, status0 = ps.status;
+    const uint32_t bw = ps.bw;
+    const int64_t arg0 = ps.arg;
     const uint64_t mis = (uintptr_t)src & 15;
     gptr<const uint8_t> base = src - mis;
     const uint64_t end = mis + src_len;
@@ -344,6 +370,355 @@ __global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict
         res->out_values = 0;
         res->out_bytes = 0;
         res->aux = ~0ull; // position of the first out-of-range dictionary index
+    }
+}
+
+
+// ---------------------------------------------------------- chunked index --
+//
+// A long page handled by many workgroups instead of one wavefront.  The page is cut into
+// chunks of CK bytes.  Where the run headers lie inside a chunk depends on where the chain of
+// headers enters it, which only the chunks before can tell; so each workgroup first parses a
+// header at EVERY byte of its chunk (what the header would be if one started there) and
+// follows those "next header" links to the end of the chunk by pointer jumping: a table from
+// entry position to exit position.  The chunks of a page then resolve one after the other
+// with a single table look-up each (resolve kernel); knowing its entry, a chunk marks the
+// headers the stream really has (pointer jumping again), counts them, adds up what the
+// chunks before it hold (every chunk publishes its totals as soon as it has them), and writes
+// its part of the run table (emit kernel).  Anything out of the ordinary -- a header that
+// does not parse, more values than a page may hold -- sends the whole page to the
+// one-wavefront kernel, which reports errors exactly as the serial decoder does.
+
+constexpr uint32_t CK = 4096;            // bytes of a chunk
+constexpr uint32_t CKT = 256;            // threads of a chunk's workgroup
+constexpr uint32_t CKP = CK / CKT;       // positions per thread
+constexpr uint32_t CK_BUF = 2 * CK;      // LDS bytes holding the chunk and the header bytes that follow it
+constexpr uint32_t CK_MASK = CK_BUF - 1;
+constexpr uint32_t CK_LOOK = 16;         // bytes past the chunk a header that starts in it may need
+constexpr uint32_t CK_ROUNDS = 12;       // 2^12 links: more than a chunk can hold
+constexpr uint32_t POS_STOP = 0xffffffffu; // exit position: the chain hit something the chunked path leaves alone
+constexpr uint32_t NO_ENTRY = 0xffffffffu;
+constexpr unsigned long long CK_READY = 1ull << 63; // a chunk's totals are there
+constexpr uint32_t CK_SPINS = 1u << 22;  // polls before a waiting workgroup gives up (the page then goes the serial way)
+
+// Workgroups take their chunk in the order they start, so that a chunk only ever waits for
+// chunks whose workgroups are already running.
+__device__ inline uint32_t ordered_chunk(uint32_t* counter, uint32_t* slot) {
+    if (threadIdx.x == 0) *slot = atomicAdd(counter, 1u);
+    __syncthreads();
+    return *slot;
+}
+
+// The chunk's bytes [cs, cs + CK + CK_LOOK) of ring space into LDS (zero past the end of the stream).
+__device__ inline void chunk_load(uint32_t* buf, gptr<const uint8_t> base, uint32_t cs, uint32_t end) {
+    for (uint32_t c = threadIdx.x * 16; c < CK + CK_LOOK; c += CKT * 16) {
+        const uint32_t v = cs + c;
+        u32x4 w = (u32x4)(0u);
+        if (v < end) w = *(gptr<const u32x4>)(base + v);
+        *reinterpret_cast<u32x4*>(&buf[(v & CK_MASK) >> 2]) = w;
+    }
+}
+
+// The header that would start at ring position p (p < end); false when it does not parse.
+__device__ inline bool chunk_header(const uint32_t* buf, uint32_t p, uint32_t end, uint32_t mis, uint32_t start, int32_t mode,
+                                    uint32_t bw, RunHeader& h) {
+    // Headers are read out of registers; the byte-wise reader only serves the last bytes of the page.
+    // A varint of more than four bytes elsewhere counts as "does not parse" (a run of 2^27 values or
+    // more, or an overlong encoding: if the stream really has one, the page goes the serial way).
+    h = parse_run<CK_MASK>(buf, p, end, mis, start, mode, bw, true);
+    if (h.slow) {
+        if (end - p >= 12) return false;
+        h = parse_run<CK_MASK>(buf, p, end, mis, start, mode, bw, false);
+    }
+    return h.err == PQD_OK;
+}
+
+// Where the header after the one at ring position p starts, for a header with at least twelve
+// bytes of page behind its first byte and a varint of at most four; 0 when the header does not
+// parse (rle.go:295-419, the same rules as parse_run, cut down to what the chain needs).
+__device__ inline uint32_t quick_next(const uint32_t* buf, uint32_t p, uint32_t end, int32_t mode, uint32_t bw) {
+    const uint32_t d = (p & CK_MASK) >> 2, sh = (p & 3) * 8;
+    const uint32_t w0 = buf[d], w1 = buf[(d + 1) & (CK_MASK >> 2)];
+    const uint32_t a0 = __builtin_amdgcn_alignbit(w1, w0, sh);
+    uint32_t u, k;
+    if (!(a0 & 0x80)) { u = a0 & 0x7f; k = 1; }
+    else if (!(a0 & 0x8000)) { u = (a0 & 0x7f) | ((a0 >> 1) & 0x3f80); k = 2; }
+    else if (!(a0 & 0x800000)) { u = (a0 & 0x7f) | ((a0 >> 1) & 0x3f80) | ((a0 >> 2) & 0x1fc000); k = 3; }
+    else if (!(a0 & 0x80000000u)) { u = (a0 & 0x7f) | ((a0 >> 1) & 0x3f80) | ((a0 >> 2) & 0x1fc000) | ((a0 >> 3) & 0xfe00000); k = 4; }
+    else return 0;
+    const uint32_t q = p + k, count = u >> 1;
+    if (count == 0) return q;                                   // an empty run has no value byte
+    if (u & 1) {                                                // bit-packed: groups of eight values (bytes for BOOLEAN)
+        const uint64_t nbytes = mode == MODE_BOOL ? (uint64_t)count : (uint64_t)count * bw;
+        return nbytes > end - q ? 0 : q + (uint32_t)nbytes;
+    }
+    if (mode == MODE_BOOL) return q + 1;                        // q < end here: twelve bytes follow p
+    const uint32_t vb = mode == MODE_LEVELS ? (bw != 0 ? 1u : 0u) : (bw + 7) / 8;
+    return q + vb;                                              // vb <= 4 fits as well
+}
+
+// First links of a chunk: nxt[q] = position (relative to the chunk) of the header after the one
+// at q; q itself when that lies past the chunk, and then ext[q] is its ring position, or POS_STOP.
+__device__ inline void chunk_links(const uint32_t* buf, uint16_t* nxt, uint32_t* ext, uint32_t cs, uint32_t ce, uint32_t end,
+                                   uint32_t mis, uint32_t start, int32_t mode, uint32_t bw) {
+    for (uint32_t i = 0; i < CKP; i++) {
+        const uint32_t q = threadIdx.x + i * CKT, p = cs + q;
+        uint32_t n = q, e = POS_STOP;
+        if (p < ce) {
+            uint32_t next = 0;
+            if (end - p >= 12) {
+                next = quick_next(buf, p, end, mode, bw);
+            } else { // the last bytes of the page: the byte-wise reader
+                RunHeader h;
+                if (chunk_header(buf, p, end, mis, start, mode, bw, h)) next = (uint32_t)h.next;
+            }
+            if (next != 0) {
+                if (next >= ce) e = next; else n = next - cs;
+            }
+        }
+        nxt[q] = (uint16_t)n;
+        ext[q] = e;
+    }
+}
+
+struct ChunkWhere {
+    uint32_t k;      // page, as an index into the list of chunked pages
+    uint32_t cs, ce; // ring-space bytes of the chunk
+    uint32_t end, mis;
+    bool first;
+};
+
+__device__ inline ChunkWhere chunk_where(const DevPage& pg, const PageSetup& ps, uint32_t chunk, uint32_t k) {
+    ChunkWhere w;
+    w.k = k;
+    w.mis = (uint32_t)((uintptr_t)pg.src & 15);
+    w.end = w.mis + (uint32_t)ps.src_len;
+    w.cs = chunk * CK;
+    w.ce = w.cs + CK < w.end ? w.cs + CK : w.end;
+    w.first = chunk == 0;
+    return w;
+}
+
+__global__ __launch_bounds__(CKT) void rle_chunk_resolve_kernel(const DevPage* __restrict__ pages, const uint32_t* __restrict__ ck_items,
+                                                              const uint32_t* __restrict__ ck_prefix, const uint32_t* __restrict__ ck_page,
+                                                              const uint32_t* __restrict__ ck_chunk, uint32_t* page_pos, uint32_t* ck_exit,
+                                                              uint32_t* ck_entry, uint16_t* ck_links, uint32_t* pk_flag, uint32_t* counter) {
+    __shared__ uint32_t buf[CK_BUF / 4];
+    __shared__ __attribute__((aligned(16))) uint16_t nxt[CK];
+    __shared__ uint32_t ext[CK];
+    __shared__ uint32_t slot;
+    const uint32_t id = ordered_chunk(counter, &slot);
+    const uint32_t k = ck_page[id], chunk = ck_chunk[id];
+    const uint32_t at = ck_prefix[k] + chunk; // this chunk's place in the per-chunk arrays
+    const DevPage& pg = pages[ck_items[k]];
+    const PageSetup ps = page_setup(pg);
+    const ChunkWhere w = chunk_where(pg, ps, chunk, k);
+    const uint32_t tid = threadIdx.x;
+    const bool usable = ps.status == PQD_OK && w.mis + ps.start < w.end;
+    if (usable) {
+        chunk_load(buf, as_global(pg.src) - w.mis, w.cs, w.end);
+        __syncthreads();
+        chunk_links(buf, nxt, ext, w.cs, w.ce, w.end, w.mis, (uint32_t)ps.start, ps.mode, ps.bw);
+        __syncthreads();
+        // the first links are kept for the emit kernel
+        for (uint32_t c = threadIdx.x * 8; c < CK; c += CKT * 8)
+            *(gptr<u32x4>)(ck_links + (size_t)at * CK + c) = *reinterpret_cast<const u32x4*>(&nxt[c]);
+        __syncthreads(); // ... before anyone replaces them
+        // Pointer jumping: every position learns the last header of the chain that starts there.  Links
+        // are replaced in place, two per dword; a link read while its owner replaces it is the old or the
+        // new one, and either lies further along the same chain, so no round needs a second barrier.
+        uint32_t* nxt32 = reinterpret_cast<uint32_t*>(nxt);
+        for (uint32_t round = 0; round < CK_ROUNDS; round++) {
+            int moved = 0;
+#pragma unroll
+            for (uint32_t i = 0; i < CKP / 2; i++) {
+                const uint32_t d = tid + i * CKT;
+                const uint32_t pair = nxt32[d];
+                const uint32_t a = pair & 0xffff, b2 = pair >> 16;
+                const uint32_t na = nxt[a], nb = nxt[b2];
+                if (na != a || nb != b2) { nxt32[d] = na | (nb << 16); moved = 1; }
+            }
+            if (!__syncthreads_or(moved)) break;
+        }
+    }
+    if (tid == 0) {
+        // page_pos[k]: how far the chain of the page's run headers is known -- the position of the first
+        // header no chunk has looked up yet.  A chunk waits until that position reaches it; chunks the
+        // chain passes over (inside a long bit-packed run) see it go past and have nothing to do.
+        uint32_t from = POS_STOP;
+        if (!usable) {
+            from = POS_STOP;
+        } else if (w.first) {
+            from = w.mis + (uint32_t)ps.start;
+        } else {
+            for (uint32_t spin = 0; spin < CK_SPINS; spin++) {
+                const uint32_t v = __hip_atomic_load(&page_pos[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (v >= w.cs) { from = v; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+        }
+        uint32_t entry = NO_ENTRY, to = from;
+        if (from != POS_STOP && from < w.ce) {
+            entry = from - w.cs;
+            to = ext[nxt[entry]]; // where the last header of the chain points
+        }
+        const bool mine = entry != NO_ENTRY || from == POS_STOP; // the chain stands in this chunk, or nobody can move it any more
+        if (mine) __hip_atomic_store(&page_pos[k], to, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (to == POS_STOP) pk_flag[k] = 1;
+        ck_entry[at] = entry;
+        ck_exit[at] = to;
+    }
+}
+
+__global__ __launch_bounds__(CKT) void rle_chunk_emit_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                           const uint32_t* __restrict__ ck_items, const uint32_t* __restrict__ ck_prefix,
+                                                           const uint32_t* __restrict__ ck_page, const uint32_t* __restrict__ ck_chunk,
+                                                           const uint32_t* __restrict__ ck_exit, const uint32_t* __restrict__ ck_entry,
+                                                           const uint16_t* __restrict__ ck_links, unsigned long long* ck_runs,
+                                                           unsigned long long* ck_vals, uint32_t* pk_flag, uint32_t* counter) {
+    __shared__ uint32_t buf[CK_BUF / 4];
+    __shared__ __attribute__((aligned(16))) uint16_t nxt[CK];
+    __shared__ __attribute__((aligned(16))) uint8_t mark[CK];
+    __shared__ unsigned long long wave_runs[CKT / 64], wave_vals[CKT / 64], base_runs, base_vals;
+    __shared__ uint32_t slot;
+    const uint32_t id = ordered_chunk(counter, &slot);
+    const uint32_t k = ck_page[id], chunk = ck_chunk[id];
+    const uint32_t first_at = ck_prefix[k], at = first_at + chunk; // places in the per-chunk arrays
+    const uint32_t item = ck_items[k];
+    const DevPage& pg = pages[item];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t entry = ck_entry[at];
+    if (pk_flag[k] != 0) return;        // the page goes the serial way: nobody waits for this chunk
+    if (entry == NO_ENTRY) {            // the chain passes over this chunk
+        if (tid == 0) {
+            __hip_atomic_store(&ck_vals[at], CK_READY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&ck_runs[at], CK_READY, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    const PageSetup ps = page_setup(pg);
+    const ChunkWhere w = chunk_where(pg, ps, chunk, k);
+    const uint32_t start = (uint32_t)ps.start;
+    chunk_load(buf, as_global(pg.src) - w.mis, w.cs, w.end);
+    for (uint32_t c = tid * 16; c < CK; c += CKT * 16) *reinterpret_cast<u32x4*>(&mark[c]) = (u32x4)(0u);
+    for (uint32_t c = tid * 8; c < CK; c += CKT * 8) // the first links, as the resolve kernel left them
+        *reinterpret_cast<u32x4*>(&nxt[c]) = *(gptr<const u32x4>)(ck_links + (size_t)at * CK + c);
+    __syncthreads();
+    // The headers of the stream, found by wave 0: 64 links at a time in registers, the chain followed
+    // through them by lane reads; the lanes it visits mark their positions.
+    if (wave == 0) {
+        uint32_t pos = entry;
+        for (uint32_t guard = 0; guard < CK; guard++) { // every pass moves on by at least one position
+            const uint32_t q = pos + lane;
+            const uint32_t n = q < CK ? (uint32_t)nxt[q] : q; // a position's own number: the chain ends there
+            unsigned long long chain = 0;
+            uint32_t cur = 0, last = 0;
+            bool ended = false;
+            while (cur < 64) {
+                chain |= 1ull << cur;
+                last = cur;
+                const uint32_t to_ = lane_u32(n, cur);
+                if (to_ == pos + cur) { ended = true; break; }
+                cur = to_ - pos;
+            }
+            if ((chain >> lane) & 1) mark[q] = 1;
+            if (ended) break;
+            pos = lane_u32(n, last);
+        }
+    }
+    __syncthreads();
+    // from here on a thread owns CKP consecutive positions
+    const u32x4 mk = *reinterpret_cast<const u32x4*>(&mark[tid * CKP]);
+    const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
+    unsigned long long my_runs = 0, my_vals = 0;
+    for (uint32_t i = 0; i < CKP; i++) {
+        if (!((mw[i >> 2] >> (8 * (i & 3))) & 0xff)) continue;
+        RunHeader h;
+        chunk_header(buf, w.cs + tid * CKP + i, w.end, w.mis, start, ps.mode, ps.bw, h);
+        if (h.kind != 2) my_runs++;
+        my_vals += h.nvals;
+    }
+    const unsigned long long in_runs = wave_inclusive_scan<uint64_t>(my_runs), in_vals = wave_inclusive_scan<uint64_t>(my_vals);
+    if (lane == 63) { wave_runs[wave] = in_runs; wave_vals[wave] = in_vals; }
+    __syncthreads();
+    unsigned long long before_runs = in_runs - my_runs, before_vals = in_vals - my_vals, all_runs = 0, all_vals = 0;
+    for (uint32_t v = 0; v < CKT / 64; v++) {
+        if (v < wave) { before_runs += wave_runs[v]; before_vals += wave_vals[v]; }
+        all_runs += wave_runs[v]; all_vals += wave_vals[v];
+    }
+    // this chunk's totals for the chunks after it; the totals of the chunks before it
+    if (tid == 0) {
+        __hip_atomic_store(&ck_vals[at], CK_READY | all_vals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&ck_runs[at], CK_READY | all_runs, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    bool gave_up = false;
+    if (wave == 0) {
+        unsigned long long sum_runs = 0, sum_vals = 0;
+        for (uint32_t c = first_at + lane; c < at; c += 64) {
+            unsigned long long r = 0;
+            uint32_t spin = 0;
+            for (; spin < CK_SPINS; spin++) {
+                r = __hip_atomic_load(&ck_runs[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (r & CK_READY) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (spin == CK_SPINS) { gave_up = true; break; }
+            __atomic_thread_fence(__ATOMIC_ACQUIRE); // the values were stored before the runs
+            sum_runs += r & ~CK_READY;
+            sum_vals += __hip_atomic_load(&ck_vals[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & ~CK_READY;
+        }
+        sum_runs = wave_inclusive_scan<uint64_t>(sum_runs);
+        sum_vals = wave_inclusive_scan<uint64_t>(sum_vals);
+        gave_up = __ballot(gave_up) != 0;
+        if (lane == 63) { base_runs = gave_up ? ~0ull : sum_runs; base_vals = sum_vals; }
+    }
+    __syncthreads();
+    if (base_runs == ~0ull) { // a chunk before this one never reported: leave the page to the serial kernel
+        if (tid == 0) pk_flag[k] = 1;
+        return;
+    }
+    const unsigned long long run0 = base_runs + before_runs, val0 = base_vals + before_vals;
+    // ---- the run-table entries of this chunk, and the per-step hints ----
+    gptr<Run> runs = as_global(pg.runs);
+    gptr<uint32_t> tile_run = as_global(pg.tile_run);
+    const uint32_t n_steps = pg.n_steps;
+    unsigned long long r_at = run0, v_at = val0;
+    for (uint32_t i = 0; i < CKP; i++) {
+        const bool on = ((mw[i >> 2] >> (8 * (i & 3))) & 0xff) != 0;
+        RunHeader h;
+        h.kind = 2; h.nvals = 0; h.in_off = 0; h.value = 0;
+        if (on) chunk_header(buf, w.cs + tid * CKP + i, w.end, w.mis, start, ps.mode, ps.bw, h);
+        const bool rec = on && h.kind != 2;
+        if (rec) {
+            Run r;
+            r.out_start = (uint32_t)v_at;
+            r.in_off = h.in_off;
+            r.value = h.value;
+            r.count_kind = ((uint32_t)h.nvals << 1) | (h.kind == 1 ? 1u : 0u);
+            store_run(runs, r_at, r);
+        }
+        publish_steps(tile_run, n_steps, rec, v_at, h.nvals, (uint32_t)r_at, lane);
+        if (rec) r_at++;
+        v_at += h.nvals;
+    }
+    // the chunk in which the chain reaches the end of the stream closes the page
+    const uint32_t to = ck_exit[at];
+    if (to == w.end && tid == 0) {
+        const unsigned long long n_runs = base_runs + all_runs, total = base_vals + all_vals;
+        if (total > MAX_TOTAL) {
+            pk_flag[k] = 1; // the serial kernel reports which run passes the limit (rle.go:373-375)
+        } else {
+            DevResult* res = &results[item];
+            res->status = PQD_OK;
+            res->bw = (int32_t)ps.bw;
+            res->arg = 0;
+            res->n_runs = n_runs;
+            res->total = total;
+            res->consumed = w.end - w.mis;
+            res->out_values = 0;
+            res->out_bytes = 0;
+            res->aux = ~0ull;
+        }
     }
 }
 
@@ -830,10 +1205,21 @@ __global__ __launch_bounds__(ET) __attribute__((amdgpu_waves_per_eu(FAMILY == FA
 
 } // namespace
 
-void launch_rle_index(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
+void launch_rle_index(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, const uint32_t* pk_flag,
                       hipStream_t stream) {
     if (n_items == 0) return;
-    hipLaunchKernelGGL(rle_index_kernel, dim3(n_items), dim3(IT), 0, stream, pages, results, items);
+    hipLaunchKernelGGL(rle_index_kernel, dim3(n_items), dim3(IT), 0, stream, pages, results, items, pk_flag);
+}
+
+uint32_t rle_chunk_bytes() { return CK; }
+
+void launch_rle_chunked(const DevPage* pages, DevResult* results, const RleChunks& c, hipStream_t stream) {
+    if (c.n_chunks == 0) return;
+    (void)hipMemsetAsync(c.state, 0, c.state_bytes, stream);
+    hipLaunchKernelGGL(rle_chunk_resolve_kernel, dim3(c.n_chunks), dim3(CKT), 0, stream, pages, c.items, c.prefix, c.page, c.chunk,
+                       c.page_pos, c.exit, c.entry, c.links, c.pk_flag, c.counters);
+    hipLaunchKernelGGL(rle_chunk_emit_kernel, dim3(c.n_chunks), dim3(CKT), 0, stream, pages, results, c.items, c.prefix, c.page,
+                       c.chunk, c.exit, c.entry, c.links, c.runs, c.vals, c.pk_flag, c.counters + 1);
 }
 
 void launch_rle_expand(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,

@@ -127,6 +127,92 @@ def test_large_run():
     assert v.size == n and int(v.min()) == 1 and int(v.max()) == 1
 
 
+def _runs_of(rng, n, hi, short_mean, long_mean):
+    """n values below hi in runs: half the runs of mean short_mean, half of mean long_mean."""
+    out = np.empty(n, np.int64)
+    i = 0
+    while i < n:
+        k = 2048
+        lens = np.where(rng.random(k) < 0.5, rng.geometric(1 / short_mean, size=k), rng.geometric(1 / long_mean, size=k))
+        rep = np.repeat(rng.integers(0, hi, size=k), lens)
+        m = min(rep.size, n - i)
+        out[i:i + m] = rep[:m]
+        i += m
+    return out
+
+
+def test_long_pages():
+    """Pages long enough to be indexed chunk by chunk (many workgroups per page): run headers
+    crossing chunk boundaries, bit-packed runs longer than a chunk, empty runs, every mode;
+    and pages the chunked kernels hand to the one-wavefront kernel (errors, too many values)."""
+    P = pkg()
+    rng = np.random.default_rng(91)
+    L, I, B = P.KIND.LEVELS, P.KIND.INT32, P.KIND.BOOLEAN
+    cases = []  # (label, kind, bit width, bytes)
+    for bw, short, long_ in ((1, 2, 40), (3, 3, 60), (7, 1.5, 20), (8, 4, 100)):
+        v = _runs_of(rng, 600_000, 1 << bw, short, long_).astype(np.uint8)
+        cases.append((f"levels-go-bw{bw}", L, bw, O.rle_encode_levels(v, bw)))
+        cases.append((f"levels-mr-bw{bw}", L, bw, O.rle_encode_levels_mr(v, bw)))
+    for bw, short, long_ in ((1, 3, 20), (5, 2, 40), (13, 9, 200), (20, 5, 60), (32, 12, 12)):
+        v = _runs_of(rng, 300_000, 1 << bw, short, long_)
+        cases.append((f"int32-bw{bw}", I, bw, O.rle_encode_int32(v.astype(np.uint32).view(np.int32), bw)))
+    # empty runs (a zero count and no value byte, rle.go:311-313) scattered through a long stream
+    parts = []
+    for k in range(12000):
+        parts.append(b"\x00" if k % 3 == 0 else (bytes([2 * (1 + k % 50)]) + bytes([k % 4])))
+        if k % 500 == 499:
+            parts.append(bytes([(8 << 1) | 1]) + bytes(rng.integers(0, 256, size=8 * 2, dtype=np.uint8)))
+    cases.append(("empty-runs", L, 2, b"".join(parts)))
+    # one bit-packed run longer than several chunks between short runs
+    body = bytes(rng.integers(0, 256, size=3 * 5000, dtype=np.uint8))
+    varint = lambda x: bytes([(x & 0x7f) | 0x80, x >> 7]) if x >= 0x80 else bytes([x])
+    long_bp = b"\x06\x05" * 700 + varint((5000 << 1) | 1) + body + b"\x08\x02" * 3000
+    cases.append(("long-bit-packed", L, 3, long_bp))
+    b = rng.integers(0, 256, size=60_000, dtype=np.uint8)
+    b[10_000:30_000] = 0xFF
+    b[40_000:41_000] = 0
+    cases.append(("boolean", B, 1, O.rle_encode_boolean(b)))
+    # errors deep inside long pages, and more values than a page may hold
+    good = O.rle_encode_levels_mr(_runs_of(rng, 400_000, 8, 2, 30).astype(np.uint8), 3)
+    cases.append(("truncated", L, 3, good[: len(good) - 1]))
+    cases.append(("bad-varint", L, 3, good[:30_000] + b"\x80" * 11 + good[30_000:]))
+    cases.append(("bit-packed-overruns", L, 3, good[:25_000] + b"\xff\xff\x03" + good[25_000:40_000]))
+    huge = bytes([0xfe, 0xff, 0xff, 0xff, 0x07, 0x01])  # one run of 2**30 - 1 values
+    cases.append(("too-many-values", L, 1, b"\x06\x01" * 9000 + huge * 3))
+    specs = [spec(P.ENC.RLE, kind, enc, bit_width=bw, misalign=k % 16) for k, (_, kind, bw, enc) in enumerate(cases)]
+    outs = decode(specs)
+    for (label, kind, bw, enc), out in zip(cases, outs):
+        assert len(enc) >= 16384, label
+        if label == "too-many-values":
+            # the one limit the reference does not have: a page decodes to at most 2**31 - 1 values here
+            assert out.status == P.STATUS.RUN_TOO_LARGE, out.status
+            continue
+        if kind == L:
+            want, dt = O.rle_decode_levels(enc, bw), np.uint8
+        elif kind == I:
+            want, dt = O.rle_decode_int32(enc, bw), np.int32
+        else:
+            want, dt = O.rle_decode_boolean(enc), np.uint8
+        assert_same(out, want, dt, label, values=want.status == 0)
+
+
+def test_long_dictionary_pages_with_runs():
+    """RLE_DICTIONARY pages of a few hundred KB full of runs, gathered through the dictionary."""
+    P = pkg()
+    rng = np.random.default_rng(92)
+    d = rng.integers(-2**62, 2**62, size=5000, dtype=np.int64)
+    specs, wants = [], []
+    for k in range(5):
+        idx = _runs_of(rng, 400_000, d.size, 3, 20 + 15 * k).astype(np.int32)
+        enc = O.rle_dict_encode_int32(idx)
+        assert len(enc) >= 16384
+        specs.append(spec(P.ENC.RLE_DICTIONARY, P.KIND.INT64, enc, dictionary=d, num_values=idx.size, misalign=3 * k))
+        wants.append(d[idx])
+    for out, want in zip(decode(specs), wants):
+        assert out.status == 0
+        assert np.array_equal(out.data.view(np.int64), want)
+
+
 def test_errors():
     P = pkg()
     L, I, B = P.KIND.LEVELS, P.KIND.INT32, P.KIND.BOOLEAN
