@@ -389,25 +389,22 @@ __global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict
 // does not parse, more values than a page may hold -- sends the whole page to the
 // one-wavefront kernel, which reports errors exactly as the serial decoder does.
 
-constexpr uint32_t CK = 4096;            // bytes of a chunk
+constexpr uint32_t CK = 8192;            // bytes of a chunk
 constexpr uint32_t CKT = 256;            // threads of a chunk's workgroup
 constexpr uint32_t CKP = CK / CKT;       // positions per thread
 constexpr uint32_t CK_BUF = 2 * CK;      // LDS bytes holding the chunk and the header bytes that follow it
 constexpr uint32_t CK_MASK = CK_BUF - 1;
 constexpr uint32_t CK_LOOK = 16;         // bytes past the chunk a header that starts in it may need
-constexpr uint32_t CK_ROUNDS = 12;       // 2^12 links: more than a chunk can hold
+constexpr uint32_t CK_ROUNDS = 13;       // 2^13 links: as many as a chunk can hold
 constexpr uint32_t POS_STOP = 0xffffffffu; // exit position: the chain hit something the chunked path leaves alone
 constexpr uint32_t NO_ENTRY = 0xffffffffu;
 constexpr unsigned long long CK_READY = 1ull << 63; // a chunk's totals are there
 constexpr uint32_t CK_SPINS = 1u << 22;  // polls before a waiting workgroup gives up (the page then goes the serial way)
 
-// Workgroups take their chunk in the order they start, so that a chunk only ever waits for
-// chunks whose workgroups are already running.
-__device__ inline uint32_t ordered_chunk(uint32_t* counter, uint32_t* slot) {
-    if (threadIdx.x == 0) *slot = atomicAdd(counter, 1u);
-    __syncthreads();
-    return *slot;
-}
+// Workgroups take the work items in the order of their numbers.  A chunk only ever waits for chunks
+// with lower numbers, and the hardware starts the workgroups of a grid in the order of their numbers
+// (on every XCD: in the order of the numbers it is dealt), so the lowest unfinished one is always
+// running; a wait that still does not end gives up after CK_SPINS polls and the page goes the serial way.
 
 // The chunk's bytes [cs, cs + CK + CK_LOOK) of ring space into LDS (zero past the end of the stream).
 __device__ inline void chunk_load(uint32_t* buf, gptr<const uint8_t> base, uint32_t cs, uint32_t end) {
@@ -457,27 +454,26 @@ __device__ inline uint32_t quick_next(const uint32_t* buf, uint32_t p, uint32_t 
     return q + vb;                                              // vb <= 4 fits as well
 }
 
+// Where the header after the one at ring position p (p < end) starts; 0 when that one does not parse.
+__device__ inline uint32_t chunk_next(const uint32_t* buf, uint32_t p, uint32_t end, uint32_t mis, uint32_t start, int32_t mode,
+                                      uint32_t bw) {
+    if (end - p >= 12) return quick_next(buf, p, end, mode, bw);
+    RunHeader h; // the last bytes of the page: the byte-wise reader
+    return chunk_header(buf, p, end, mis, start, mode, bw, h) ? (uint32_t)h.next : 0u;
+}
+
 // First links of a chunk: nxt[q] = position (relative to the chunk) of the header after the one
-// at q; q itself when that lies past the chunk, and then ext[q] is its ring position, or POS_STOP.
-__device__ inline void chunk_links(const uint32_t* buf, uint16_t* nxt, uint32_t* ext, uint32_t cs, uint32_t ce, uint32_t end,
-                                   uint32_t mis, uint32_t start, int32_t mode, uint32_t bw) {
+// at q; q itself when that lies past the chunk or the header does not parse.
+__device__ inline void chunk_links(const uint32_t* buf, uint16_t* nxt, uint32_t cs, uint32_t ce, uint32_t end, uint32_t mis,
+                                   uint32_t start, int32_t mode, uint32_t bw) {
     for (uint32_t i = 0; i < CKP; i++) {
         const uint32_t q = threadIdx.x + i * CKT, p = cs + q;
-        uint32_t n = q, e = POS_STOP;
+        uint32_t n = q;
         if (p < ce) {
-            uint32_t next = 0;
-            if (end - p >= 12) {
-                next = quick_next(buf, p, end, mode, bw);
-            } else { // the last bytes of the page: the byte-wise reader
-                RunHeader h;
-                if (chunk_header(buf, p, end, mis, start, mode, bw, h)) next = (uint32_t)h.next;
-            }
-            if (next != 0) {
-                if (next >= ce) e = next; else n = next - cs;
-            }
+            const uint32_t next = chunk_next(buf, p, end, mis, start, mode, bw);
+            if (next != 0 && next < ce) n = next - cs;
         }
         nxt[q] = (uint16_t)n;
-        ext[q] = e;
     }
 }
 
@@ -502,12 +498,10 @@ __device__ inline ChunkWhere chunk_where(const DevPage& pg, const PageSetup& ps,
 __global__ __launch_bounds__(CKT) void rle_chunk_resolve_kernel(const DevPage* __restrict__ pages, const uint32_t* __restrict__ ck_items,
                                                               const uint32_t* __restrict__ ck_prefix, const uint32_t* __restrict__ ck_page,
                                                               const uint32_t* __restrict__ ck_chunk, uint32_t* page_pos, uint32_t* ck_exit,
-                                                              uint32_t* ck_entry, uint16_t* ck_links, uint32_t* pk_flag, uint32_t* counter) {
+                                                              uint32_t* ck_entry, uint16_t* ck_links, uint32_t* pk_flag) {
     __shared__ uint32_t buf[CK_BUF / 4];
     __shared__ __attribute__((aligned(16))) uint16_t nxt[CK];
-    __shared__ uint32_t ext[CK];
-    __shared__ uint32_t slot;
-    const uint32_t id = ordered_chunk(counter, &slot);
+    const uint32_t id = blockIdx.x;
     const uint32_t k = ck_page[id], chunk = ck_chunk[id];
     const uint32_t at = ck_prefix[k] + chunk; // this chunk's place in the per-chunk arrays
     const DevPage& pg = pages[ck_items[k]];
@@ -518,7 +512,7 @@ __global__ __launch_bounds__(CKT) void rle_chunk_resolve_kernel(const DevPage* _
     if (usable) {
         chunk_load(buf, as_global(pg.src) - w.mis, w.cs, w.end);
         __syncthreads();
-        chunk_links(buf, nxt, ext, w.cs, w.ce, w.end, w.mis, (uint32_t)ps.start, ps.mode, ps.bw);
+        chunk_links(buf, nxt, w.cs, w.ce, w.end, w.mis, (uint32_t)ps.start, ps.mode, ps.bw);
         __syncthreads();
         // the first links are kept for the emit kernel
         for (uint32_t c = threadIdx.x * 8; c < CK; c += CKT * 8)
@@ -560,7 +554,9 @@ __global__ __launch_bounds__(CKT) void rle_chunk_resolve_kernel(const DevPage* _
         uint32_t entry = NO_ENTRY, to = from;
         if (from != POS_STOP && from < w.ce) {
             entry = from - w.cs;
-            to = ext[nxt[entry]]; // where the last header of the chain points
+            // the last header of the chain that enters here, and where that one points
+            const uint32_t next = chunk_next(buf, w.cs + nxt[entry], w.end, w.mis, (uint32_t)ps.start, ps.mode, ps.bw);
+            to = next != 0 ? next : POS_STOP;
         }
         const bool mine = entry != NO_ENTRY || from == POS_STOP; // the chain stands in this chunk, or nobody can move it any more
         if (mine) __hip_atomic_store(&page_pos[k], to, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -575,13 +571,13 @@ __global__ __launch_bounds__(CKT) void rle_chunk_emit_kernel(const DevPage* __re
                                                            const uint32_t* __restrict__ ck_page, const uint32_t* __restrict__ ck_chunk,
                                                            const uint32_t* __restrict__ ck_exit, const uint32_t* __restrict__ ck_entry,
                                                            const uint16_t* __restrict__ ck_links, unsigned long long* ck_runs,
-                                                           unsigned long long* ck_vals, uint32_t* pk_flag, uint32_t* counter) {
+                                                           unsigned long long* ck_vals, uint32_t* pk_flag) {
     __shared__ uint32_t buf[CK_BUF / 4];
     __shared__ __attribute__((aligned(16))) uint16_t nxt[CK];
-    __shared__ __attribute__((aligned(16))) uint8_t mark[CK];
+    __shared__ uint16_t list[CK];   // the headers of the stream in this chunk, in order
+    __shared__ uint32_t n_list;
     __shared__ unsigned long long wave_runs[CKT / 64], wave_vals[CKT / 64], base_runs, base_vals;
-    __shared__ uint32_t slot;
-    const uint32_t id = ordered_chunk(counter, &slot);
+    const uint32_t id = blockIdx.x;
     const uint32_t k = ck_page[id], chunk = ck_chunk[id];
     const uint32_t first_at = ck_prefix[k], at = first_at + chunk; // places in the per-chunk arrays
     const uint32_t item = ck_items[k];
@@ -600,14 +596,13 @@ __global__ __launch_bounds__(CKT) void rle_chunk_emit_kernel(const DevPage* __re
     const ChunkWhere w = chunk_where(pg, ps, chunk, k);
     const uint32_t start = (uint32_t)ps.start;
     chunk_load(buf, as_global(pg.src) - w.mis, w.cs, w.end);
-    for (uint32_t c = tid * 16; c < CK; c += CKT * 16) *reinterpret_cast<u32x4*>(&mark[c]) = (u32x4)(0u);
     for (uint32_t c = tid * 8; c < CK; c += CKT * 8) // the first links, as the resolve kernel left them
         *reinterpret_cast<u32x4*>(&nxt[c]) = *(gptr<const u32x4>)(ck_links + (size_t)at * CK + c);
     __syncthreads();
     // The headers of the stream, found by wave 0: 64 links at a time in registers, the chain followed
-    // through them by lane reads; the lanes it visits mark their positions.
+    // through them by lane reads; the lanes it visits append their positions to the list.
     if (wave == 0) {
-        uint32_t pos = entry;
+        uint32_t pos = entry, count = 0;
         for (uint32_t guard = 0; guard < CK; guard++) { // every pass moves on by at least one position
             const uint32_t q = pos + lane;
             const uint32_t n = q < CK ? (uint32_t)nxt[q] : q; // a position's own number: the chain ends there
@@ -621,38 +616,40 @@ __global__ __launch_bounds__(CKT) void rle_chunk_emit_kernel(const DevPage* __re
                 if (to_ == pos + cur) { ended = true; break; }
                 cur = to_ - pos;
             }
-            if ((chain >> lane) & 1) mark[q] = 1;
+            if ((chain >> lane) & 1) list[count + __popcll(chain & ((1ull << lane) - 1))] = (uint16_t)q;
+            count += __popcll(chain);
             if (ended) break;
             pos = lane_u32(n, last);
         }
+        if (lane == 0) n_list = count;
     }
     __syncthreads();
-    // from here on a thread owns CKP consecutive positions
-    const u32x4 mk = *reinterpret_cast<const u32x4*>(&mark[tid * CKP]);
-    const uint32_t mw[4] = {mk.x, mk.y, mk.z, mk.w};
-    unsigned long long my_runs = 0, my_vals = 0;
-    for (uint32_t i = 0; i < CKP; i++) {
-        if (!((mw[i >> 2] >> (8 * (i & 3))) & 0xff)) continue;
-        RunHeader h;
-        chunk_header(buf, w.cs + tid * CKP + i, w.end, w.mis, start, ps.mode, ps.bw, h);
-        if (h.kind != 2) my_runs++;
-        my_vals += h.nvals;
+    const uint32_t n_hdr = n_list;
+    // ---- what the chunk adds: a header per thread, 256 at a time ----
+    unsigned long long all_runs = 0, all_vals = 0;
+    for (uint32_t b0 = 0; b0 < n_hdr; b0 += CKT) {
+        unsigned long long r = 0, v = 0;
+        if (b0 + tid < n_hdr) {
+            RunHeader h;
+            chunk_header(buf, w.cs + list[b0 + tid], w.end, w.mis, start, ps.mode, ps.bw, h);
+            r = h.kind != 2 ? 1 : 0;
+            v = h.nvals;
+        }
+        all_runs += r; all_vals += v;
     }
-    const unsigned long long in_runs = wave_inclusive_scan<uint64_t>(my_runs), in_vals = wave_inclusive_scan<uint64_t>(my_vals);
-    if (lane == 63) { wave_runs[wave] = in_runs; wave_vals[wave] = in_vals; }
+    all_runs = wave_inclusive_scan<uint64_t>(all_runs);
+    all_vals = wave_inclusive_scan<uint64_t>(all_vals);
+    if (lane == 63) { wave_runs[wave] = all_runs; wave_vals[wave] = all_vals; }
     __syncthreads();
-    unsigned long long before_runs = in_runs - my_runs, before_vals = in_vals - my_vals, all_runs = 0, all_vals = 0;
-    for (uint32_t v = 0; v < CKT / 64; v++) {
-        if (v < wave) { before_runs += wave_runs[v]; before_vals += wave_vals[v]; }
-        all_runs += wave_runs[v]; all_vals += wave_vals[v];
-    }
+    all_runs = 0; all_vals = 0;
+    for (uint32_t v = 0; v < CKT / 64; v++) { all_runs += wave_runs[v]; all_vals += wave_vals[v]; }
     // this chunk's totals for the chunks after it; the totals of the chunks before it
     if (tid == 0) {
         __hip_atomic_store(&ck_vals[at], CK_READY | all_vals, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&ck_runs[at], CK_READY | all_runs, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
-    bool gave_up = false;
     if (wave == 0) {
+        bool gave_up = false;
         unsigned long long sum_runs = 0, sum_vals = 0;
         for (uint32_t c = first_at + lane; c < at; c += 64) {
             unsigned long long r = 0;
@@ -677,18 +674,25 @@ __global__ __launch_bounds__(CKT) void rle_chunk_emit_kernel(const DevPage* __re
         if (tid == 0) pk_flag[k] = 1;
         return;
     }
-    const unsigned long long run0 = base_runs + before_runs, val0 = base_vals + before_vals;
     // ---- the run-table entries of this chunk, and the per-step hints ----
     gptr<Run> runs = as_global(pg.runs);
     gptr<uint32_t> tile_run = as_global(pg.tile_run);
     const uint32_t n_steps = pg.n_steps;
-    unsigned long long r_at = run0, v_at = val0;
-    for (uint32_t i = 0; i < CKP; i++) {
-        const bool on = ((mw[i >> 2] >> (8 * (i & 3))) & 0xff) != 0;
+    unsigned long long r_base = base_runs, v_base = base_vals;
+    for (uint32_t b0 = 0; b0 < n_hdr; b0 += CKT) {
         RunHeader h;
         h.kind = 2; h.nvals = 0; h.in_off = 0; h.value = 0;
-        if (on) chunk_header(buf, w.cs + tid * CKP + i, w.end, w.mis, start, ps.mode, ps.bw, h);
-        const bool rec = on && h.kind != 2;
+        if (b0 + tid < n_hdr) chunk_header(buf, w.cs + list[b0 + tid], w.end, w.mis, start, ps.mode, ps.bw, h);
+        const bool rec = h.kind != 2;
+        const unsigned long long in_r = wave_inclusive_scan<uint64_t>(rec ? 1 : 0), in_v = wave_inclusive_scan<uint64_t>(h.nvals);
+        __syncthreads(); // the totals of the batch before have been read
+        if (lane == 63) { wave_runs[wave] = in_r; wave_vals[wave] = in_v; }
+        __syncthreads();
+        unsigned long long r_at = r_base + in_r - (rec ? 1 : 0), v_at = v_base + in_v - h.nvals;
+        for (uint32_t v = 0; v < CKT / 64; v++) {
+            if (v < wave) { r_at += wave_runs[v]; v_at += wave_vals[v]; }
+            r_base += wave_runs[v]; v_base += wave_vals[v];
+        }
         if (rec) {
             Run r;
             r.out_start = (uint32_t)v_at;
@@ -698,8 +702,6 @@ __global__ __launch_bounds__(CKT) void rle_chunk_emit_kernel(const DevPage* __re
             store_run(runs, r_at, r);
         }
         publish_steps(tile_run, n_steps, rec, v_at, h.nvals, (uint32_t)r_at, lane);
-        if (rec) r_at++;
-        v_at += h.nvals;
     }
     // the chunk in which the chain reaches the end of the stream closes the page
     const uint32_t to = ck_exit[at];
@@ -1217,9 +1219,9 @@ void launch_rle_chunked(const DevPage* pages, DevResult* results, const RleChunk
     if (c.n_chunks == 0) return;
     (void)hipMemsetAsync(c.state, 0, c.state_bytes, stream);
     hipLaunchKernelGGL(rle_chunk_resolve_kernel, dim3(c.n_chunks), dim3(CKT), 0, stream, pages, c.items, c.prefix, c.page, c.chunk,
-                       c.page_pos, c.exit, c.entry, c.links, c.pk_flag, c.counters);
+                       c.page_pos, c.exit, c.entry, c.links, c.pk_flag);
     hipLaunchKernelGGL(rle_chunk_emit_kernel, dim3(c.n_chunks), dim3(CKT), 0, stream, pages, results, c.items, c.prefix, c.page,
-                       c.chunk, c.exit, c.entry, c.links, c.runs, c.vals, c.pk_flag, c.counters + 1);
+                       c.chunk, c.exit, c.entry, c.links, c.runs, c.vals, c.pk_flag);
 }
 
 void launch_rle_expand(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
