@@ -512,14 +512,12 @@ __global__ __launch_bounds__(MT) void dlba_copy_kernel(const DevPage* __restrict
 
 constexpr uint32_t LAST_CAP = 2048;  // leading bytes of the previous value kept in LDS
 constexpr uint32_t DSTAGE = 8192;    // suffix bytes staged per pass
+constexpr uint32_t DPREF = 2048;     // suffix bytes fetched a round ahead
 
+// Exclusive prefix sum over the wave and the wave's total, with the DPP scan (no LDS round trips).
 __device__ inline uint64_t wave_excl_scan64(uint64_t v, uint32_t lane, uint64_t* total) {
-    uint64_t x = v;
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint64_t y = __shfl_up(x, d);
-        if ((int)lane >= d) x += y;
-    }
-    *total = __shfl(x, 63);
+    const uint64_t x = wave_inclusive_scan<uint64_t>(v);
+    *total = lane_u64(x, 63);
     return x - v;
 }
 
@@ -563,15 +561,21 @@ __global__ __launch_bounds__(WT) void dba_kernel(const DevPage* __restrict__ pag
     uint64_t prev_len = 0, prev_out = 0; // the previous value: its length and where it went
     int32_t status = PQD_OK;
     int64_t arg = 0;
+    // Two things are fetched a round ahead, so that no round starts by waiting for memory: the
+    // lengths of the next 64 values, and the DPREF suffix bytes that follow this round's.
+    uint64_t staged_base = 0, staged_len = 0; // data bytes [staged_base, staged_base + staged_len) are in `stage`
+    int32_t pl_next = lane < ns ? prefix[lane] : 0, sl_next = lane < ns ? suffix[lane] : 0;
     while (done < ns && status == PQD_OK) {
         const uint64_t k = done + lane;
         const bool valid = k < ns;
-        const int64_t pl = valid ? prefix[k] : 0, sl = valid ? suffix[k] : 0;
+        const int64_t pl = valid ? pl_next : 0, sl = valid ? sl_next : 0;
+        pl_next = k + WT < ns ? prefix[k + WT] : 0;
+        sl_next = k + WT < ns ? suffix[k + WT] : 0;
         const uint64_t s_pos = sl > 0 ? (uint64_t)sl : 0, p_pos = pl > 0 ? (uint64_t)pl : 0;
         uint64_t s_tot, v_tot;
         const uint64_t s_off = src_base + wave_excl_scan64(s_pos, lane, &s_tot);
         const uint64_t o_off = out_base + wave_excl_scan64(p_pos + s_pos, lane, &v_tot);
-        uint64_t before = __shfl_up(p_pos + s_pos, 1);
+        uint64_t before = dpp0<0x138, 0xf>(p_pos + s_pos); // wave_shr:1: the value one lane down
         if (lane == 0) before = prev_len;
         int32_t err = PQD_OK;
         int64_t err_arg = 0;
@@ -589,8 +593,22 @@ __global__ __launch_bounds__(WT) void dba_kernel(const DevPage* __restrict__ pag
         if (bad) {
             const uint32_t first = (uint32_t)__builtin_ctzll(bad);
             m = first;
-            status = __shfl(err, first);
-            arg = __shfl(err_arg, first);
+            status = (int32_t)lane_u32((uint32_t)err, first);
+            arg = (int64_t)lane_u64((uint64_t)err_arg, first);
+        }
+        // the suffix bytes after this round's, requested now and put into `stage` once the round is through
+        const uint64_t next0 = src_base + s_tot;
+        u32x4_a1 pf[DPREF / (16 * WT)];
+        uint64_t pf_len = 0;
+        if (!bad && next0 < data_total) {
+            const uint64_t room = (data_total - next0) & ~15ull;
+            pf_len = room < DPREF ? room : DPREF;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < DPREF / (16 * WT); u++) {
+            const uint64_t at = (uint64_t)(u * WT + lane) * 16;
+            pf[u] = (u32x4_a1)(0u);
+            if (at < pf_len) pf[u] = *(gptr<const u32x4_a1>)(data + next0 + at);
         }
         // values [done, done + m) are good; the staged spans may cut the round into several passes
         uint32_t taken = 0;
@@ -607,23 +625,45 @@ __global__ __launch_bounds__(WT) void dba_kernel(const DevPage* __restrict__ pag
                 // from the staged suffix bytes, so the only thing carried from value to value is a
                 // register, and the LDS reads of the suffixes do not wait for one another. ----
                 const uint64_t span1 = lane_u64(s_off + s_pos, taken + cnt - 1);
-                stage_fill(stage, data + span0, span1 - span0, lane);
-                __syncthreads();
+                if (span0 < staged_base || span1 > staged_base + staged_len) { // not what the last round fetched ahead
+                    stage_fill(stage, data + span0, span1 - span0, lane);
+                    staged_base = span0;
+                    staged_len = span1 - span0;
+                    __syncthreads();
+                }
                 const uint32_t* stage32 = reinterpret_cast<const uint32_t*>(stage);
-                const uint32_t so32 = (uint32_t)(s_off - span0), p32 = (uint32_t)p_pos, s32 = (uint32_t)s_pos;
+                const uint32_t so32 = (uint32_t)(s_off - staged_base), p32 = (uint32_t)p_pos, s32 = (uint32_t)s_pos;
                 if (with_offsets && lane >= taken && lane < taken + cnt) offsets[done + lane] = (uint32_t)o_off;
                 uint32_t cur = reinterpret_cast<const uint32_t*>(last)[lane];
-                for (uint32_t v = taken; v < taken + cnt; v++) {
-                    const uint32_t p_v = lane_u32(p32, v), s_v = lane_u32(s32, v), so = lane_u32(so32, v);
-                    const uint64_t oo = lane_u64(o_off, v);
-                    const int32_t k = (int32_t)p_v - (int32_t)(4 * lane);   // bytes of this lane's dword below the prefix length
-                    const uint32_t suf = lds_u32(stage32, so + (k < 0 ? (uint32_t)(-k) : 0u));
-                    if (k <= 0) cur = suf;
-                    else if (k < 4) cur = (cur & ((1u << (8 * k)) - 1)) | (suf << (8 * k));
-                    const uint32_t len = p_v + s_v;
-                    gptr<uint8_t> o = dst + oo + 4 * lane;
-                    if (4 * lane + 4 <= len) *(gptr<u32_a1>)(o) = cur;
-                    else if (4 * lane < len) for (uint32_t q = 0; 4 * lane + q < len; q++) o[q] = (uint8_t)(cur >> (8 * q));
+                // four values per trip: their suffix dwords are read from LDS together, then the
+                // register is updated and stored value by value
+                for (uint32_t v0 = taken; v0 < taken + cnt; v0 += 4) {
+                    uint32_t p_v[4], len_v[4], suf[4];
+                    int32_t kk[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) {
+                        const uint32_t v = v0 + u < taken + cnt ? v0 + u : taken + cnt - 1; // the last one again: harmless
+                        p_v[u] = lane_u32(p32, v);
+                        len_v[u] = p_v[u] + lane_u32(s32, v);
+                        kk[u] = (int32_t)p_v[u] - (int32_t)(4 * lane);   // bytes of this lane's dword below the prefix length
+                        suf[u] = lds_u32(stage32, lane_u32(so32, v) + (kk[u] < 0 ? (uint32_t)(-kk[u]) : 0u));
+                    }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) {
+                        if (v0 + u >= taken + cnt) break;
+                        const uint64_t oo = lane_u64(o_off, v0 + u);
+                        const int32_t k = kk[u];
+                        if (k <= 0) cur = suf[u];
+                        else if (k < 4) cur = (cur & ((1u << (8 * k)) - 1)) | (suf[u] << (8 * k));
+                        const uint32_t len = len_v[u];
+                        gptr<uint8_t> o = dst + oo + 4 * lane;
+                        if (4 * lane + 4 <= len) *(gptr<u32_a1>)(o) = cur;
+                        else if (4 * lane < len) {
+                            const uint32_t rest = len - 4 * lane; // 1..3 bytes
+                            if (rest >= 2) *(gptr<uint16_t>)(o) = (uint16_t)cur;
+                            if (rest & 1) o[rest - 1] = (uint8_t)(cur >> (8 * (rest - 1)));
+                        }
+                    }
                 }
                 const uint32_t last_len = lane_u32(p32 + s32, taken + cnt - 1);
                 reinterpret_cast<uint32_t*>(last)[lane] = cur; // the slow pass and the next fast pass start from here
@@ -662,9 +702,20 @@ __global__ __launch_bounds__(WT) void dba_kernel(const DevPage* __restrict__ pag
                 taken += 1;
             }
         }
+        // every pass of the round has read what it wanted from `stage`: in go the bytes fetched ahead
+        if (pf_len > 0) {
+#pragma unroll
+            for (uint32_t u = 0; u < DPREF / (16 * WT); u++) {
+                const uint64_t at = (uint64_t)(u * WT + lane) * 16;
+                if (at < pf_len) *reinterpret_cast<u32x4*>(stage + at) = pf[u];
+            }
+            staged_base = next0;
+            staged_len = pf_len;
+            __syncthreads();
+        }
         if (m > 0) {
-            src_base = __shfl(s_off + s_pos, m - 1);
-            out_base = __shfl(o_off + p_pos + s_pos, m - 1);
+            src_base = lane_u64(s_off + s_pos, m - 1);
+            out_base = lane_u64(o_off + p_pos + s_pos, m - 1);
         }
         done += m;
         if (status != PQD_OK) break;
