@@ -47,9 +47,18 @@ struct pqd_batch {
     uint64_t rle_tiles[4] = {0, 0, 0, 0};
     uint64_t rle_steps = 0;
     RleChunks ck; // long RLE pages indexed chunk by chunk
+    // a small batch forks its independent kernel families onto the context's side streams
+    bool side_by_side = false;
+    hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
     // generic tile grids for the element-parallel families
     uint64_t max_src[16] = {0}; // longest src of each family, sizes the tile grids
     std::vector<DevResult> h_results;
+    ~pqd_batch() {
+        if (arena) (void)hipFree(arena);
+        if (fork) (void)hipEventDestroy(fork);
+        for (hipEvent_t e : join)
+            if (e) (void)hipEventDestroy(e);
+    }
 };
 
 namespace {
@@ -82,6 +91,7 @@ int32_t elem_width_of(int32_t kind, int32_t bit_width) {
 // Which kernel family decodes (encoding, kind); FAM_NONE = not supported, as
 // encoding.NotSupported would answer (encoding/notsupported.go:163-197).
 // The RLE hybrid families share the index kernel; each has an expand kernel and a tile grid of its own.
+constexpr size_t SIDE_BY_SIDE_MAX_ITEMS = 1024;     // batches up to this size fork their families onto side streams
 constexpr int RLE_GRIDS = 4;
 constexpr size_t RLE_CHUNKED_MAX_PAGES = 512;      // batches with more RLE pages than this index them one wavefront each
 constexpr uint64_t RLE_CHUNKED_MIN_BYTES = 16384;   // shorter pages are not worth cutting up
@@ -197,11 +207,18 @@ int pqd_ctx_create(int device, pqd_ctx** out) {
     pqd_ctx* ctx = new (std::nothrow) pqd_ctx;
     if (ctx == nullptr) return PQD_ERR_DEVICE;
     ctx->device = device;
+    for (hipStream_t& st : ctx->side)
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
     *out = ctx;
     return PQD_OK;
 }
 
-void pqd_ctx_destroy(pqd_ctx* ctx) { delete ctx; }
+void pqd_ctx_destroy(pqd_ctx* ctx) {
+    if (ctx == nullptr) return;
+    for (hipStream_t st : ctx->side)
+        if (st != nullptr) (void)hipStreamDestroy(st);
+    delete ctx;
+}
 
 int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_batch** out) {
     if (ctx == nullptr || out == nullptr || (pages == nullptr && n_pages > 0)) return PQD_ERR_INVALID_ARGUMENT;
@@ -363,6 +380,22 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
         b->ck.n_chunks = (uint32_t)n_chunks;
     }
 
+    // ---- a small batch cannot fill the chip with any one family: its families run side by side ----
+    {
+        const bool rle = [&] { for (int g = 0; g < RLE_GRIDS; g++) if (!b->fam[RLE_FAMILY[g]].items.empty()) return true; return false; }();
+        const bool delta = !b->fam[FAM_DELTA32].items.empty() || !b->fam[FAM_DELTA64].items.empty();
+        const bool flat = !b->fam[FAM_BITPACKED].items.empty() || !b->fam[FAM_BSS].items.empty() || !b->fam[FAM_PLAIN_FIXED].items.empty();
+        const bool walk = !b->fam[FAM_PLAIN_BYTE_ARRAY].items.empty();
+        const int groups = (int)rle + (int)delta + (int)flat + (int)walk;
+        bool streams = true;
+        for (hipStream_t st : ctx->side) streams = streams && st != nullptr;
+        if (groups >= 2 && streams && b->items.size() <= SIDE_BY_SIDE_MAX_ITEMS) {
+            bool ev = hipEventCreateWithFlags(&b->fork, hipEventDisableTiming) == hipSuccess;
+            for (hipEvent_t& e : b->join) ev = ev && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+            b->side_by_side = ev;
+        }
+    }
+
     // ---- carve one arena ----
     const size_t n_items = b->items.size();
     size_t off = 0;
@@ -466,7 +499,7 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
         ok = ok && hip_ok(hipMemcpy(a + o_ck_page, ck_page.data(), nck * sizeof(uint32_t), hipMemcpyHostToDevice));
         ok = ok && hip_ok(hipMemcpy(a + o_ck_chunk, ck_chunk.data(), nck * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
-    if (!ok) { (void)hipFree(b->arena); delete b; return PQD_ERR_DEVICE; }
+    if (!ok) { delete b; return PQD_ERR_DEVICE; }
     b->h_results.resize(n_items);
     *out = b;
     return PQD_OK;
@@ -475,26 +508,42 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
 int pqd_batch_launch(pqd_batch* b, void* hip_stream) {
     if (b == nullptr) return PQD_ERR_INVALID_ARGUMENT;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    // The kernel families of a batch are independent of one another, except that the DELTA byte-array
+    // families start from length streams the DELTA kernels decode.  A small batch runs them side by
+    // side: the caller's stream forks into the context's side streams and joins them again, so to the
+    // caller everything still happens in its stream (the pattern is legal under stream capture too).
+    hipStream_t s_rle = s, s_flat = s, s_walk = s;
+    if (b->side_by_side) {
+        PQD_HIP(hipEventRecord(b->fork, s));
+        s_rle = b->ctx->side[0]; s_flat = b->ctx->side[1]; s_walk = b->ctx->side[2];
+        for (hipStream_t st : b->ctx->side) PQD_HIP(hipStreamWaitEvent(st, b->fork, 0));
+    }
     launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA32].dev, (uint32_t)b->fam[FAM_DELTA32].items.size(), false, s);
     launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA32_CHAINED].dev, (uint32_t)b->fam[FAM_DELTA32_CHAINED].items.size(), false, s);
     launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA64].dev, (uint32_t)b->fam[FAM_DELTA64].items.size(), true, s);
-    launch_rle_chunked(b->d_items, b->d_results, b->ck, s);
+    launch_rle_chunked(b->d_items, b->d_results, b->ck, s_rle);
     for (int g = 0; g < RLE_GRIDS; g++) {
         const FamilyList& f = b->fam[RLE_FAMILY[g]];
-        launch_rle_index(b->d_items, b->d_results, f.dev, (uint32_t)f.items.size(), b->ck.pk_flag, s);
+        launch_rle_index(b->d_items, b->d_results, f.dev, (uint32_t)f.items.size(), b->ck.pk_flag, s_rle);
     }
     for (int g = 0; g < RLE_GRIDS; g++) {
         const FamilyList& f = b->fam[RLE_FAMILY[g]];
         launch_rle_expand(b->d_items, b->d_results, f.dev, (uint32_t)f.items.size(), b->d_rle_tile_prefix[g], b->d_rle_tile_item[g],
-                          b->rle_tiles[g], RLE_FAMILY[g], s);
+                          b->rle_tiles[g], RLE_FAMILY[g], s_rle);
     }
     auto fam_n = [&](int f) { return (uint32_t)b->fam[f].items.size(); };
-    launch_bitpacked(b->d_items, b->d_results, b->fam[FAM_BITPACKED].dev, fam_n(FAM_BITPACKED), b->max_src[FAM_BITPACKED] * 8, s);
-    launch_bss(b->d_items, b->d_results, b->fam[FAM_BSS].dev, fam_n(FAM_BSS), b->max_src[FAM_BSS], s);
-    launch_plain_fixed(b->d_items, b->d_results, b->fam[FAM_PLAIN_FIXED].dev, fam_n(FAM_PLAIN_FIXED), b->max_src[FAM_PLAIN_FIXED], s);
-    launch_plain_byte_array(b->d_items, b->d_results, b->fam[FAM_PLAIN_BYTE_ARRAY].dev, fam_n(FAM_PLAIN_BYTE_ARRAY), s);
+    launch_bitpacked(b->d_items, b->d_results, b->fam[FAM_BITPACKED].dev, fam_n(FAM_BITPACKED), b->max_src[FAM_BITPACKED] * 8, s_flat);
+    launch_bss(b->d_items, b->d_results, b->fam[FAM_BSS].dev, fam_n(FAM_BSS), b->max_src[FAM_BSS], s_flat);
+    launch_plain_fixed(b->d_items, b->d_results, b->fam[FAM_PLAIN_FIXED].dev, fam_n(FAM_PLAIN_FIXED), b->max_src[FAM_PLAIN_FIXED], s_flat);
+    launch_plain_byte_array(b->d_items, b->d_results, b->fam[FAM_PLAIN_BYTE_ARRAY].dev, fam_n(FAM_PLAIN_BYTE_ARRAY), s_walk);
     launch_dlba(b->d_items, b->d_results, b->fam[FAM_DLBA].dev, fam_n(FAM_DLBA), b->max_src[FAM_DLBA], s);
     launch_dba(b->d_items, b->d_results, b->fam[FAM_DBA].dev, fam_n(FAM_DBA), s);
+    if (b->side_by_side) {
+        for (int i = 0; i < 3; i++) {
+            PQD_HIP(hipEventRecord(b->join[i], b->ctx->side[i]));
+            PQD_HIP(hipStreamWaitEvent(s, b->join[i], 0));
+        }
+    }
     return hipGetLastError() == hipSuccess ? PQD_OK : PQD_ERR_DEVICE;
 }
 
@@ -531,7 +580,6 @@ int pqd_batch_finish(pqd_batch* b, void* hip_stream, pqd_page* pages, uint64_t n
 
 void pqd_batch_destroy(pqd_batch* b) {
     if (b == nullptr) return;
-    if (b->arena) (void)hipFree(b->arena);
     delete b;
 }
 

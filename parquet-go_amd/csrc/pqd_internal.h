@@ -9,6 +9,7 @@
 // Opaque handles of the C ABI.
 struct pqd_ctx {
     int device;
+    hipStream_t side[3]; // small batches run their kernel families side by side on these (null: not created)
 };
 
 struct pqd_dict {
