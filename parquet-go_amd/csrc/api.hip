@@ -52,6 +52,7 @@ struct pqd_batch {
     hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
     // generic tile grids for the element-parallel families
     uint64_t max_src[16] = {0}; // longest src of each family, sizes the tile grids
+    uint64_t dba_max_values = 0; // most values a DELTA_BYTE_ARRAY page of the batch is expected to hold
     std::vector<DevResult> h_results;
     ~pqd_batch() {
         if (arena) (void)hipFree(arena);
@@ -294,7 +295,11 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
                 DevPage d = make_item(p, family);
                 d.chain = s_idx;
                 d.lengths_cap = cap;
-                lengths_entries += 2 * cap + 8;
+                // [prefix | suffix | three words per block of 64 values for the block-parallel kernels]
+                lengths_entries += 2 * cap + 8 + 3 * (cap / 64 + 2);
+                uint64_t expect = cap;
+                if (p.num_values >= 0 && (uint64_t)p.num_values < expect) expect = (uint64_t)p.num_values;
+                b->dba_max_values = std::max<uint64_t>(b->dba_max_values, expect);
                 m.primary = (int32_t)b->items.size();
                 b->items.push_back(d);
             }
@@ -468,7 +473,8 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
             d.lengths2 = lengths + d.lengths_cap + 4;
             pre.dst = reinterpret_cast<uint8_t*>(d.lengths);
             suf.dst = reinterpret_cast<uint8_t*>(d.lengths2);
-            lengths += 2 * d.lengths_cap + 8;
+            d.tile_run = reinterpret_cast<uint32_t*>(lengths + 2 * d.lengths_cap + 8);
+            lengths += 2 * d.lengths_cap + 8 + 3 * (d.lengths_cap / 64 + 2);
         }
     }
 
@@ -537,7 +543,7 @@ int pqd_batch_launch(pqd_batch* b, void* hip_stream) {
     launch_plain_fixed(b->d_items, b->d_results, b->fam[FAM_PLAIN_FIXED].dev, fam_n(FAM_PLAIN_FIXED), b->max_src[FAM_PLAIN_FIXED], s_flat);
     launch_plain_byte_array(b->d_items, b->d_results, b->fam[FAM_PLAIN_BYTE_ARRAY].dev, fam_n(FAM_PLAIN_BYTE_ARRAY), s_walk);
     launch_dlba(b->d_items, b->d_results, b->fam[FAM_DLBA].dev, fam_n(FAM_DLBA), b->max_src[FAM_DLBA], s);
-    launch_dba(b->d_items, b->d_results, b->fam[FAM_DBA].dev, fam_n(FAM_DBA), s);
+    launch_dba(b->d_items, b->d_results, b->fam[FAM_DBA].dev, fam_n(FAM_DBA), b->dba_max_values, s);
     if (b->side_by_side) {
         for (int i = 0; i < 3; i++) {
             PQD_HIP(hipEventRecord(b->join[i], b->ctx->side[i]));

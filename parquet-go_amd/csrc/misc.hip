@@ -538,6 +538,7 @@ __global__ __launch_bounds__(WT) void dba_kernel(const DevPage* __restrict__ pag
     const int32_t s_item = pg.chain, p_item = pages[s_item].chain;
     const DevResult rp = results[p_item], rs = results[s_item];
     const uint32_t lane = threadIdx.x;
+    if (res->aux == 1) return; // decoded block by block (dba_plan_kernel, dba_expand_kernel)
     const bool with_offsets = pg.kind == PQD_KIND_BYTE_ARRAY;
     if (!with_offsets && (pg.bit_width < 0 || (uint32_t)pg.bit_width > MAX_FLBA)) { // byte_array.go:149-151
         if (lane == 0) finish(res, PQD_ERR_INVALID_ARGUMENT, pg.bit_width, 0, 0, 0);
@@ -739,6 +740,271 @@ __global__ __launch_bounds__(WT) void dba_kernel(const DevPage* __restrict__ pag
     }
 }
 
+// ---------------------------------------- DELTA_BYTE_ARRAY, block-parallel --
+//
+// The same decode (byte_array_purego.go:5-34) cut into blocks of 64 values that are decoded
+// independently of one another.  Byte k of value i is a suffix byte of the latest value j <= i
+// whose prefix length is <= k, so "what does a stretch of values do to the running value" is
+// associative: it keeps the bytes below the least prefix length of the stretch and replaces the
+// rest.  Three kernels:
+//   dba_block_kernel   per block: suffix bytes, output bytes, least prefix length, validity;
+//   dba_plan_kernel    per page: exclusive sums over the blocks, the page-level checks, and the
+//                      decision whether the page takes this path (anything unusual -- an error,
+//                      FIXED_LEN_BYTE_ARRAY, very long values -- is left to dba_kernel, which
+//                      reports errors exactly as the sequential decoder does);
+//   dba_expand_kernel  per block, one wavefront, a lane per value: the bytes the block inherits
+//                      from earlier values are looked up by walking the least prefix lengths of
+//                      the blocks before it; the block's values are put together in an LDS image
+//                      of its output bytes, dword column by dword column, the inherited bytes of
+//                      a column travelling from lane to lane in a segmented wave scan; the image
+//                      is copied out with aligned 16-byte stores.
+
+constexpr uint32_t DBLK = 64;      // values per block
+constexpr uint32_t DIMG = 8192;    // output bytes a block may produce on this path
+constexpr uint32_t DCARRY = 1024;  // longest prefix length on this path
+constexpr uint32_t DBAD = 0x80000000u;
+
+__device__ inline uint32_t wave_min_u32(uint32_t v) {
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+__device__ inline bool dba_parallel_candidate(const DevPage& pg, const DevResult& rp, const DevResult& rs) {
+    return pg.kind == PQD_KIND_BYTE_ARRAY && pg.tile_run != nullptr && rp.status == PQD_OK && rs.status == PQD_OK &&
+           rp.out_values == rs.out_values && rs.out_values > 0 && rs.out_values <= pg.lengths_cap &&
+           rs.out_values + 1 <= pg.offsets_cap && rs.out_values < 0x7fffffffull;
+}
+
+// grid.x = pages, grid.y = slots; a wavefront takes a block of 64 values at a time.
+__global__ __launch_bounds__(MT) void dba_block_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                       const uint32_t* __restrict__ items) {
+    const uint32_t item = items[blockIdx.x];
+    const DevPage& pg = pages[item];
+    const int32_t s_item = pg.chain, p_item = pages[s_item].chain;
+    const DevResult rp = results[p_item], rs = results[s_item];
+    if (!dba_parallel_candidate(pg, rp, rs)) return;
+    const uint64_t ns = rs.out_values, nblk = (ns + DBLK - 1) / DBLK;
+    gptr<const int32_t> prefix = (gptr<const int32_t>)as_global(pg.lengths);
+    gptr<const int32_t> suffix = (gptr<const int32_t>)as_global(pg.lengths2);
+    gptr<uint32_t> bstat = as_global(pg.tile_run);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (uint64_t blk = (uint64_t)blockIdx.y * (MT / 64) + wave; blk < nblk; blk += (uint64_t)gridDim.y * (MT / 64)) {
+        const uint64_t k = blk * DBLK + lane;
+        const bool valid = k < ns;
+        const int32_t p = valid ? prefix[k] : 0, s = valid ? suffix[k] : 0;
+        bool bad = p < 0 || s < 0 || (uint32_t)p > DCARRY || (uint32_t)s > DIMG;
+        const uint32_t len = (uint32_t)p + (uint32_t)s;
+        uint32_t before = dpp0<0x138, 0xf>(len); // wave_shr:1
+        if (lane == 0) before = k > 0 ? (uint32_t)prefix[k - 1] + (uint32_t)suffix[k - 1] : 0u;
+        bad = bad || (valid && (uint32_t)p > before); // byte_array_purego.go:22-24
+        const uint32_t sum_s = lane_u32(wave_inclusive_scan<uint32_t>(bad ? 0u : (uint32_t)s), 63);
+        const uint32_t sum_l = lane_u32(wave_inclusive_scan<uint32_t>(bad ? 0u : len), 63);
+        const uint32_t least = wave_min_u32(valid ? (uint32_t)p : 0xffffffffu);
+        const bool any_bad = __ballot(bad) != 0 || sum_l > DIMG;
+        if (lane == 0) {
+            bstat[3 * blk] = sum_s;
+            bstat[3 * blk + 1] = sum_l;
+            bstat[3 * blk + 2] = any_bad ? DBAD : least;
+        }
+    }
+}
+
+// One workgroup per page: block sums become block starts, and the page is either finished here
+// (aux = 1: dba_expand_kernel writes its bytes) or left to dba_kernel (aux = 0).
+__global__ __launch_bounds__(MT) void dba_plan_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                      const uint32_t* __restrict__ items) {
+    __shared__ uint64_t ws[MT / 64], wo[MT / 64];
+    const uint32_t item = items[blockIdx.x];
+    const DevPage& pg = pages[item];
+    DevResult* res = &results[item];
+    const int32_t s_item = pg.chain, p_item = pages[s_item].chain;
+    const DevResult rp = results[p_item], rs = results[s_item];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (!dba_parallel_candidate(pg, rp, rs)) {
+        if (tid == 0) res->aux = 0;
+        return;
+    }
+    const uint64_t ns = rs.out_values, nblk = (ns + DBLK - 1) / DBLK;
+    gptr<uint32_t> bstat = as_global(pg.tile_run);
+    uint64_t carry_s = 0, carry_o = 0;
+    bool bad = false;
+    for (uint64_t base = 0; base < nblk; base += MT) {
+        const uint64_t b = base + tid;
+        const bool v = b < nblk;
+        const uint64_t s = v ? bstat[3 * b] : 0, o = v ? bstat[3 * b + 1] : 0;
+        const uint32_t least = v ? bstat[3 * b + 2] : 0;
+        bad = bad || (least & DBAD) != 0;
+        const uint64_t xs = wave_inclusive_scan<uint64_t>(s), xo = wave_inclusive_scan<uint64_t>(o);
+        if (lane == 63) { ws[wave] = xs; wo[wave] = xo; }
+        __syncthreads();
+        uint64_t before_s = carry_s, before_o = carry_o, all_s = 0, all_o = 0;
+        for (uint32_t w = 0; w < MT / 64; w++) {
+            if (w < wave) { before_s += ws[w]; before_o += wo[w]; }
+            all_s += ws[w];
+            all_o += wo[w];
+        }
+        if (v) {
+            bstat[3 * b] = (uint32_t)(before_s + xs - s);
+            bstat[3 * b + 1] = (uint32_t)(before_o + xo - o);
+        }
+        carry_s += all_s;
+        carry_o += all_o;
+        __syncthreads();
+    }
+    const bool any_bad = __syncthreads_or(bad ? 1 : 0) != 0;
+    if (tid == 0) {
+        const uint64_t data_total = pg.src_len - rs.consumed;
+        const bool ok = !any_bad && carry_s <= data_total && carry_o <= pg.dst_cap && carry_o < 0xffffffffull;
+        res->aux = ok ? 1 : 0;
+        if (ok) finish(res, PQD_OK, 0, ns, carry_o, rs.consumed + carry_s);
+    }
+}
+
+// Four bytes of the data section at any offset; the last bytes of the section one at a time.
+__device__ inline uint32_t data_u32(gptr<const uint8_t> data, uint64_t at, uint64_t total) {
+    if (at + 4 <= total) return *(gptr<const u32_a1>)(data + at);
+    uint32_t w = 0;
+    for (uint32_t e = 0; at + e < total; e++) w |= (uint32_t)data[at + e] << (8 * e);
+    return w;
+}
+
+__global__ __launch_bounds__(WT) void dba_expand_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                        const uint32_t* __restrict__ items) {
+    __shared__ __attribute__((aligned(16))) uint8_t img[DIMG + 48];
+    __shared__ __attribute__((aligned(16))) uint8_t carry[DCARRY + 16];
+    const uint32_t item = items[blockIdx.x];
+    if (results[item].aux != 1) return;
+    const DevPage& pg = pages[item];
+    const int32_t s_item = pg.chain;
+    const DevResult rs = results[s_item];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t ns = rs.out_values, nblk = (ns + DBLK - 1) / DBLK;
+    gptr<const int32_t> prefix = (gptr<const int32_t>)as_global(pg.lengths);
+    gptr<const int32_t> suffix = (gptr<const int32_t>)as_global(pg.lengths2);
+    gptr<const uint32_t> bstat = (gptr<const uint32_t>)as_global(pg.tile_run);
+    gptr<const uint8_t> data = as_global(pg.src) + rs.consumed;
+    const uint64_t data_total = pg.src_len - rs.consumed;
+    gptr<uint8_t> dst = as_global(pg.dst);
+    gptr<uint32_t> offsets = as_global(pg.offsets);
+    uint32_t* img32 = reinterpret_cast<uint32_t*>(img);
+    const uint32_t* carry32 = reinterpret_cast<const uint32_t*>(carry);
+
+    for (uint64_t blk = blockIdx.y; blk < nblk; blk += gridDim.y) {
+        const uint64_t k = blk * DBLK + lane;
+        const bool valid = k < ns;
+        const uint32_t p = valid ? (uint32_t)prefix[k] : 0u, s = valid ? (uint32_t)suffix[k] : 0u;
+        const uint32_t len = p + s;
+        const uint32_t base_s = bstat[3 * blk], base_o = bstat[3 * blk + 1];
+        const uint32_t xs = wave_inclusive_scan<uint32_t>(s), xo = wave_inclusive_scan<uint32_t>(len);
+        const uint32_t block_bytes = lane_u32(xo, 63);
+        const uint32_t s_at = base_s + xs - s;  // where this value's suffix bytes start in the data section
+        const uint32_t o_rel = xo - len;        // where the value starts in the block's output
+        if (valid) offsets[k] = base_o + o_rel;
+        if (k + 1 == ns) offsets[ns] = base_o + xo;
+        const uint32_t align = (uint32_t)((uintptr_t)(dst + base_o) & 15);
+        const uint32_t q = align + o_rel;       // the value's place in the image
+
+        // ---- what the block inherits: bytes [0, need) of the value before it ----
+        const uint32_t need = lane_u32(p, 0);
+        {
+            uint32_t r = need;     // bytes [0, r) are still to be found
+            uint64_t cur = blk;    // among the blocks before `cur`
+            while (r > 0 && cur > 0) {
+                const bool have = (uint64_t)lane < cur;
+                const uint64_t bi = have ? cur - 1 - lane : 0;
+                const uint32_t bm = have ? bstat[3 * bi + 2] : 0xffffffffu;
+                const unsigned long long hit = __ballot(have && bm < r);
+                if (hit == 0) { cur = cur > 64 ? cur - 64 : 0; continue; }
+                const uint32_t first = (uint32_t)__builtin_ctzll(hit);
+                const uint64_t b2 = cur - 1 - first;
+                // lanes take the values of that block last to first
+                const uint64_t kk = b2 * DBLK + (63 - lane);
+                const uint32_t pj = (uint32_t)prefix[kk], sj = (uint32_t)suffix[kk];
+                uint32_t incl = pj; // least prefix length among this value and the later ones
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
+                    if ((int)lane >= d && o < incl) incl = o;
+                }
+                uint32_t later = (uint32_t)__shfl_up((int)incl, 1);
+                if (lane == 0) later = 0xffffffffu;
+                const uint32_t rj = later < r ? later : r;   // the value supplies bytes [pj, rj)
+                const uint32_t sj_at = bstat[3 * (b2 + 1)] - wave_inclusive_scan<uint32_t>(sj);
+                unsigned long long cm = __ballot(pj < rj);
+                while (cm) {
+                    const uint32_t j = (uint32_t)__builtin_ctzll(cm);
+                    cm &= cm - 1;
+                    const uint32_t lo = lane_u32(pj, j), hi = lane_u32(rj, j), at = lane_u32(sj_at, j);
+                    for (uint32_t kb = lo + lane; kb < hi; kb += WT) carry[kb] = data[(uint64_t)at + (kb - lo)];
+                }
+                const uint32_t least = lane_u32(bm, first);
+                r = least < r ? least : r;
+                cur = b2;
+            }
+        }
+
+        // ---- suffix bytes into their places in the image ----
+        for (uint32_t t = 0; __ballot(t < s) != 0; t += 4) {
+            if (t < s) {
+                const uint32_t w = data_u32(data, (uint64_t)s_at + t, data_total);
+                const uint32_t n = s - t < 4 ? s - t : 4;
+                for (uint32_t e = 0; e < n; e++) img[q + p + t + e] = (uint8_t)(w >> (8 * e));
+            }
+        }
+        __syncthreads();
+
+        // ---- inherited bytes, a dword column at a time ----
+        uint32_t longest = p;
+        for (int d = 32; d > 0; d >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)longest, d);
+            longest = o > longest ? o : longest;
+        }
+        for (uint32_t c = 0; 4 * c < longest; c++) {
+            uint32_t at = q + 4 * c;
+            at = at < DIMG + 32 ? at : DIMG + 32;
+            uint32_t v = lds_u32(img32, at);
+            const int32_t rel = (int32_t)p - (int32_t)(4 * c); // bytes of this dword below the prefix length
+            uint32_t m = rel <= 0 ? 0xffffffffu : (rel >= 4 ? 0u : 0xffffffffu << (8 * rel));
+            // inclusive scan: a lane takes from the lanes before it the bytes it does not define itself
+#define PQD_DBA_STEP(CTRL, ROWS)                                   \
+            {                                                          \
+                const uint32_t vl = dpp0<CTRL, ROWS>(v), ml = dpp0<CTRL, ROWS>(m); \
+                v = (v & m) | (vl & ~m);                               \
+                m |= ml;                                               \
+            }
+            PQD_DBA_STEP(0x111, 0xf)
+            PQD_DBA_STEP(0x112, 0xf)
+            PQD_DBA_STEP(0x114, 0xf)
+            PQD_DBA_STEP(0x118, 0xf)
+            PQD_DBA_STEP(0x142, 0xa)
+            PQD_DBA_STEP(0x143, 0xc)
+#undef PQD_DBA_STEP
+            const uint32_t cw = carry32[c];
+            const uint32_t w = (v & m) | (cw & ~m);
+            if (rel > 0) {
+                const uint32_t n = rel < 4 ? (uint32_t)rel : 4u;
+                for (uint32_t e = 0; e < n; e++) img[q + 4 * c + e] = (uint8_t)(w >> (8 * e));
+            }
+        }
+        __syncthreads();
+
+        // ---- the image goes out: image and destination agree modulo 16 ----
+        {
+            gptr<uint8_t> out = dst + base_o;
+            const uint32_t head = ((16 - align) & 15) < block_bytes ? ((16 - align) & 15) : block_bytes;
+            const uint32_t body = (block_bytes - head) / 16;
+            const uint32_t tail0 = head + body * 16;
+            if (lane < head) out[lane] = img[align + lane];
+            if (tail0 + lane < block_bytes) out[tail0 + lane] = img[align + tail0 + lane];
+            for (uint32_t c = lane; c < body; c += WT)
+                *(gptr<u32x4>)(out + head + c * 16) = *reinterpret_cast<const u32x4*>(img + align + head + c * 16);
+        }
+        __syncthreads();
+    }
+}
+
 // Wrapping int32 sum of a decoded length stream (delta.go:28-33), for
 // EstimateDecodeByteArraySize (length_byte_array.go:65-70, byte_array.go:176-183).
 __global__ __launch_bounds__(MT) void sum_lengths_kernel(const int32_t* __restrict__ v, uint64_t n, uint32_t* __restrict__ out) {
@@ -794,8 +1060,13 @@ void launch_dlba(const DevPage* pages, DevResult* results, const uint32_t* items
     hipLaunchKernelGGL(dlba_copy_kernel, dim3(n_items, tile_slots(max_bytes, MT * 64)), dim3(MT), 0, stream, pages, results, items);
 }
 
-void launch_dba(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, hipStream_t stream) {
+void launch_dba(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_values,
+                hipStream_t stream) {
     if (n_items == 0) return;
+    const uint64_t blocks = (max_values + DBLK - 1) / DBLK;
+    hipLaunchKernelGGL(dba_block_kernel, dim3(n_items, tile_slots(blocks, MT / 64)), dim3(MT), 0, stream, pages, results, items);
+    hipLaunchKernelGGL(dba_plan_kernel, dim3(n_items), dim3(MT), 0, stream, pages, results, items);
+    hipLaunchKernelGGL(dba_expand_kernel, dim3(n_items, tile_slots(blocks, 1)), dim3(WT), 0, stream, pages, results, items);
     hipLaunchKernelGGL(dba_kernel, dim3(n_items), dim3(WT), 0, stream, pages, results, items);
 }
 

@@ -51,7 +51,8 @@ struct DevPage {
     int32_t* lengths2;  // DELTA_BYTE_ARRAY suffix lengths
     uint64_t lengths_cap; // entries each
     uint64_t tile_base;   // first tile of this page in its family's tile grid
-    uint32_t* tile_run;   // RLE: per step of RLE_TILE values, the run-table entry holding its first value
+    uint32_t* tile_run;   // RLE: per step of RLE_TILE values, the run-table entry holding its first value;
+                          // DELTA_BYTE_ARRAY: three words per block of 64 values (suffix bytes, output bytes, least prefix)
     uint32_t n_steps;     // RLE: steps of RLE_TILE values this page may produce (bound known on the host)
     uint32_t group;       // RLE: steps one expand workgroup takes (several for 1-byte elements)
     int32_t elem_width;   // output element width in bytes
@@ -190,7 +191,8 @@ void launch_plain_byte_array(const DevPage* pages, DevResult* results, const uin
                              hipStream_t stream);
 void launch_dlba(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_bytes,
                  hipStream_t stream);
-void launch_dba(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, hipStream_t stream);
+void launch_dba(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_values,
+                hipStream_t stream);
 void launch_sum_lengths(const int32_t* v, uint64_t n, uint32_t* out, hipStream_t stream);
 
 constexpr uint32_t RLE_TILE = 2048; // output values per expand workgroup

@@ -337,3 +337,86 @@ def test_mixed_batch_all_families():
     assert np.array_equal(outs[6].data[:9000], lv)
     assert outs[7].data.tobytes() == f64.tobytes()
     assert outs[8].data.tobytes() == b"".join(strs[::-1])
+
+
+def test_delta_byte_array_block_by_block():
+    # Pages long enough to be cut into blocks of 64 values: prefixes that reach back over many
+    # blocks, empty values, prefix lengths falling step by step, block-boundary sizes, and
+    # values too long for the block-parallel kernels (those pages take the sequential kernel).
+    P = pkg()
+    rng = np.random.default_rng(21)
+    cases = []
+    cases.append(("urls-20000", _urls(rng, 20000)))
+    for n in (1, 2, 63, 64, 65, 127, 128, 129, 1000):
+        cases.append((f"urls-{n}", _urls(rng, n)))
+    cases.append(("random-5000", _strings(rng, 5000)))
+    cases.append(("sorted-random-5000", sorted(_strings(rng, 5000, 0, 6))))
+    # one long-lived first byte, everything else changing; empty values in between
+    vals = []
+    for k in range(3000):
+        r = int(rng.integers(0, 10))
+        vals.append(b"" if r == 0 else b"k" + bytes(rng.integers(0, 4, size=int(rng.integers(0, 9)), dtype=np.uint8)))
+    cases.append(("one-byte-prefix", vals))
+    # a staircase: value k shares k % 200 bytes with the one before
+    base = bytes(rng.integers(0, 256, size=256, dtype=np.uint8))
+    stair, last = [], base
+    for k in range(2500):
+        keep = (k * 7) % 200
+        last = last[:keep] + bytes(rng.integers(0, 256, size=int(rng.integers(1, 40)), dtype=np.uint8))
+        last = last[:250]
+        stair.append(last)
+    cases.append(("staircase", stair))
+    # identical values: every byte of every value comes from the first one
+    cases.append(("identical", [b"the same value every time"] * 4000))
+    # prefixes only ever grow for a while (bytes inherited from ever older values), then reset
+    grow = []
+    for k in range(2000):
+        j = k % 300
+        grow.append(bytes([65 + (i * 7 + (k // 300)) % 26 for i in range(j // 3)]) + bytes([48 + k % 10]))
+    cases.append(("growing", grow))
+    # long values: over the block limits, decoded by the sequential kernel
+    cases.append(("long-values", [bytes(rng.integers(0, 3, size=int(rng.integers(100, 400)), dtype=np.uint8)) for _ in range(300)]))
+    longp = [bytes(rng.integers(0, 2, size=1500, dtype=np.uint8))]
+    for k in range(200):
+        longp.append(longp[-1][: 1100 + k] + bytes([2, 3, k % 256]))
+    cases.append(("long-prefixes", longp))
+    encs = [O.dba_encode(v) for _, v in cases]
+    outs = decode([spec(P.ENC.DELTA_BYTE_ARRAY, P.KIND.BYTE_ARRAY, e, misalign=k % 16) for k, e in enumerate(encs)])
+    for (label, vals), enc, out in zip(cases, encs, outs):
+        want = O.dba_decode(enc)
+        assert want.values.tobytes() == b"".join(vals), label
+        _same_byte_array(out, want, label)
+    # the same streams as FIXED_LEN_BYTE_ARRAY pages (no offsets: the sequential kernel)
+    fixed = [bytes(rng.integers(0, 4, size=12, dtype=np.uint8)) for _ in range(3000)]
+    enc = O.dba_encode(sorted(fixed))
+    out = decode([spec(P.ENC.DELTA_BYTE_ARRAY, P.KIND.FIXED_LEN_BYTE_ARRAY, enc, bit_width=12)])[0]
+    assert out.status == 0 and out.data.tobytes() == b"".join(sorted(fixed))
+
+
+def test_delta_byte_array_block_by_block_errors():
+    # errors deep inside a long page are reported as the sequential decoder reports them
+    P = pkg()
+    rng = np.random.default_rng(22)
+    vals = _urls(rng, 3000)
+    prefix, suffix, data = [], [], b""
+    last = b""
+    for v in vals:
+        p = 0
+        while p < min(len(v), len(last)) and v[p] == last[p]:
+            p += 1
+        prefix.append(p)
+        suffix.append(len(v) - p)
+        data += v[p:]
+        last = v
+    def page(pre, suf, tail):
+        return O.delta_encode_int32(np.array(pre, np.int32)) + O.delta_encode_int32(np.array(suf, np.int32)) + tail
+    bad_prefix = list(prefix); bad_prefix[2500] = len(vals[2499]) + 1      # longer than the value before
+    neg_prefix = list(prefix); neg_prefix[1234] = -3
+    neg_suffix = list(suffix); neg_suffix[777] = -1
+    encs = [page(bad_prefix, suffix, data), page(neg_prefix, suffix, data), page(prefix, neg_suffix, data),
+            page(prefix, suffix, data[:-5]), page(prefix, suffix[:-1], data)]
+    outs = decode([spec(P.ENC.DELTA_BYTE_ARRAY, P.KIND.BYTE_ARRAY, e) for e in encs])
+    for k, (enc, out) in enumerate(zip(encs, outs)):
+        want = O.dba_decode(enc)
+        assert want.status != 0, k
+        _same_byte_array(out, want, f"error case {k}")
