@@ -20,6 +20,8 @@
 // The length streams of the two DELTA byte-array encodings are ordinary
 // DELTA_BINARY_PACKED int32 items of the same batch (delta.hip); the kernels
 // here start from their results.
+#include <algorithm>
+
 #include "pqd_internal.h"
 
 namespace pqd {
@@ -538,7 +540,7 @@ __global__ __launch_bounds__(WT) void dba_kernel(const DevPage* __restrict__ pag
     const int32_t s_item = pg.chain, p_item = pages[s_item].chain;
     const DevResult rp = results[p_item], rs = results[s_item];
     const uint32_t lane = threadIdx.x;
-    if (res->aux == 1) return; // decoded block by block (dba_plan_kernel, dba_expand_kernel)
+    if (res->aux != 0) return; // decoded block by block (dba_plan_kernel, dba_expand_kernel)
     const bool with_offsets = pg.kind == PQD_KIND_BYTE_ARRAY;
     if (!with_offsets && (pg.bit_width < 0 || (uint32_t)pg.bit_width > MAX_FLBA)) { // byte_array.go:149-151
         if (lane == 0) finish(res, PQD_ERR_INVALID_ARGUMENT, pg.bit_width, 0, 0, 0);
@@ -762,7 +764,10 @@ __global__ __launch_bounds__(WT) void dba_kernel(const DevPage* __restrict__ pag
 constexpr uint32_t DBLK = 64;      // values per block
 constexpr uint32_t DIMG = 8192;    // output bytes a block may produce on this path
 constexpr uint32_t DCARRY = 1024;  // longest prefix length on this path
-constexpr uint32_t DBAD = 0x80000000u;
+// Pages whose blocks all stay below these take the kernel instantiation with the small LDS image
+// (more wavefronts per CU); one block above them and the page takes the large one.
+constexpr uint32_t DIMG_SMALL = 5120, DCARRY_SMALL = 256;
+constexpr uint32_t DBAD = 0x80000000u, DBIG = 0x40000000u;
 
 __device__ inline uint32_t wave_min_u32(uint32_t v) {
     for (int d = 32; d > 0; d >>= 1) {
@@ -791,29 +796,49 @@ __global__ __launch_bounds__(MT) void dba_block_kernel(const DevPage* __restrict
     gptr<const int32_t> suffix = (gptr<const int32_t>)as_global(pg.lengths2);
     gptr<uint32_t> bstat = as_global(pg.tile_run);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (uint64_t blk = (uint64_t)blockIdx.y * (MT / 64) + wave; blk < nblk; blk += (uint64_t)gridDim.y * (MT / 64)) {
-        const uint64_t k = blk * DBLK + lane;
-        const bool valid = k < ns;
-        const int32_t p = valid ? prefix[k] : 0, s = valid ? suffix[k] : 0;
-        bool bad = p < 0 || s < 0 || (uint32_t)p > DCARRY || (uint32_t)s > DIMG;
-        const uint32_t len = (uint32_t)p + (uint32_t)s;
-        uint32_t before = dpp0<0x138, 0xf>(len); // wave_shr:1
-        if (lane == 0) before = k > 0 ? (uint32_t)prefix[k - 1] + (uint32_t)suffix[k - 1] : 0u;
-        bad = bad || (valid && (uint32_t)p > before); // byte_array_purego.go:22-24
-        const uint32_t sum_s = lane_u32(wave_inclusive_scan<uint32_t>(bad ? 0u : (uint32_t)s), 63);
-        const uint32_t sum_l = lane_u32(wave_inclusive_scan<uint32_t>(bad ? 0u : len), 63);
-        const uint32_t least = wave_min_u32(valid ? (uint32_t)p : 0xffffffffu);
-        const bool any_bad = __ballot(bad) != 0 || sum_l > DIMG;
-        if (lane == 0) {
-            bstat[3 * blk] = sum_s;
-            bstat[3 * blk + 1] = sum_l;
-            bstat[3 * blk + 2] = any_bad ? DBAD : least;
+    // four blocks per wavefront and trip, their loads in flight together
+    constexpr uint32_t UN = 4;
+    for (uint64_t blk0 = ((uint64_t)blockIdx.y * (MT / 64) + wave) * UN; blk0 < nblk; blk0 += (uint64_t)gridDim.y * (MT / 64) * UN) {
+        int32_t pv[UN], sv[UN];
+        uint32_t bv[UN];
+#pragma unroll
+        for (uint32_t u = 0; u < UN; u++) {
+            const uint64_t k = (blk0 + u) * DBLK + lane;
+            const bool valid = k < ns;
+            pv[u] = valid ? prefix[k] : 0;
+            sv[u] = valid ? suffix[k] : 0;
+            bv[u] = 0;
+            if (lane == 0 && valid && k > 0) bv[u] = (uint32_t)prefix[k - 1] + (uint32_t)suffix[k - 1];
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < UN; u++) {
+            const uint64_t blk = blk0 + u;
+            if (blk >= nblk) break;
+            const uint64_t k = blk * DBLK + lane;
+            const bool valid = k < ns;
+            const int32_t p = pv[u], s = sv[u];
+            bool bad = p < 0 || s < 0 || (uint32_t)p > DCARRY || (uint32_t)s > DIMG;
+            const uint32_t len = (uint32_t)p + (uint32_t)s;
+            uint32_t before = dpp0<0x138, 0xf>(len); // wave_shr:1
+            if (lane == 0) before = bv[u];
+            bad = bad || (valid && (uint32_t)p > before); // byte_array_purego.go:22-24
+            const uint32_t sum_s = lane_u32(wave_inclusive_scan<uint32_t>(bad ? 0u : (uint32_t)s), 63);
+            const uint32_t sum_l = lane_u32(wave_inclusive_scan<uint32_t>(bad ? 0u : len), 63);
+            const uint32_t least = wave_min_u32(valid ? (uint32_t)p : 0xffffffffu);
+            const bool any_bad = __ballot(bad) != 0 || sum_l > DIMG;
+            const bool big = sum_l + 16 > DIMG_SMALL || __ballot((uint32_t)p > DCARRY_SMALL) != 0;
+            if (lane == 0) {
+                bstat[3 * blk] = sum_s;
+                bstat[3 * blk + 1] = sum_l;
+                bstat[3 * blk + 2] = any_bad ? DBAD : (least | (big ? DBIG : 0u));
+            }
         }
     }
 }
 
 // One workgroup per page: block sums become block starts, and the page is either finished here
-// (aux = 1: dba_expand_kernel writes its bytes) or left to dba_kernel (aux = 0).
+// (aux = 1 or 2: dba_expand_kernel with the small or the large image writes its bytes) or left to
+// dba_kernel (aux = 0).
 __global__ __launch_bounds__(MT) void dba_plan_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
                                                       const uint32_t* __restrict__ items) {
     __shared__ uint64_t ws[MT / 64], wo[MT / 64];
@@ -830,13 +855,14 @@ __global__ __launch_bounds__(MT) void dba_plan_kernel(const DevPage* __restrict_
     const uint64_t ns = rs.out_values, nblk = (ns + DBLK - 1) / DBLK;
     gptr<uint32_t> bstat = as_global(pg.tile_run);
     uint64_t carry_s = 0, carry_o = 0;
-    bool bad = false;
+    bool bad = false, big = false;
     for (uint64_t base = 0; base < nblk; base += MT) {
         const uint64_t b = base + tid;
         const bool v = b < nblk;
         const uint64_t s = v ? bstat[3 * b] : 0, o = v ? bstat[3 * b + 1] : 0;
         const uint32_t least = v ? bstat[3 * b + 2] : 0;
         bad = bad || (least & DBAD) != 0;
+        big = big || (least & DBIG) != 0;
         const uint64_t xs = wave_inclusive_scan<uint64_t>(s), xo = wave_inclusive_scan<uint64_t>(o);
         if (lane == 63) { ws[wave] = xs; wo[wave] = xo; }
         __syncthreads();
@@ -855,10 +881,11 @@ __global__ __launch_bounds__(MT) void dba_plan_kernel(const DevPage* __restrict_
         __syncthreads();
     }
     const bool any_bad = __syncthreads_or(bad ? 1 : 0) != 0;
+    const bool any_big = __syncthreads_or(big ? 1 : 0) != 0;
     if (tid == 0) {
         const uint64_t data_total = pg.src_len - rs.consumed;
         const bool ok = !any_bad && carry_s <= data_total && carry_o <= pg.dst_cap && carry_o < 0xffffffffull;
-        res->aux = ok ? 1 : 0;
+        res->aux = ok ? (any_big ? 2 : 1) : 0;
         if (ok) finish(res, PQD_OK, 0, ns, carry_o, rs.consumed + carry_s);
     }
 }
@@ -871,12 +898,13 @@ __device__ inline uint32_t data_u32(gptr<const uint8_t> data, uint64_t at, uint6
     return w;
 }
 
+template <uint32_t IMG, uint32_t CARRY, uint32_t CLASS>
 __global__ __launch_bounds__(WT) void dba_expand_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
                                                         const uint32_t* __restrict__ items) {
-    __shared__ __attribute__((aligned(16))) uint8_t img[DIMG + 48];
-    __shared__ __attribute__((aligned(16))) uint8_t carry[DCARRY + 16];
+    __shared__ __attribute__((aligned(16))) uint8_t img[IMG + 48];
+    __shared__ __attribute__((aligned(16))) uint8_t carry[CARRY + 16];
     const uint32_t item = items[blockIdx.x];
-    if (results[item].aux != 1) return;
+    if (results[item].aux != CLASS) return;
     const DevPage& pg = pages[item];
     const int32_t s_item = pg.chain;
     const DevResult rs = results[s_item];
@@ -898,6 +926,15 @@ __global__ __launch_bounds__(WT) void dba_expand_kernel(const DevPage* __restric
         const uint32_t p = valid ? (uint32_t)prefix[k] : 0u, s = valid ? (uint32_t)suffix[k] : 0u;
         const uint32_t len = p + s;
         const uint32_t base_s = bstat[3 * blk], base_o = bstat[3 * blk + 1];
+        // Asked for now, used by the look-up of the inherited bytes below, so that it does not start
+        // with two more trips to memory: the least prefix lengths of the 64 blocks before this one,
+        // and the lengths of the block just before it (last value first).
+        const uint32_t bm0 = (uint64_t)lane < blk ? bstat[3 * (blk - 1 - lane) + 2] & ~DBIG : 0xffffffffu;
+        uint32_t pj0 = 0, sj0 = 0;
+        if (blk > 0) {
+            pj0 = (uint32_t)prefix[(blk - 1) * DBLK + (63 - lane)];
+            sj0 = (uint32_t)suffix[(blk - 1) * DBLK + (63 - lane)];
+        }
         const uint32_t xs = wave_inclusive_scan<uint32_t>(s), xo = wave_inclusive_scan<uint32_t>(len);
         const uint32_t block_bytes = lane_u32(xo, 63);
         const uint32_t s_at = base_s + xs - s;  // where this value's suffix bytes start in the data section
@@ -906,6 +943,10 @@ __global__ __launch_bounds__(WT) void dba_expand_kernel(const DevPage* __restric
         if (k + 1 == ns) offsets[ns] = base_o + xo;
         const uint32_t align = (uint32_t)((uintptr_t)(dst + base_o) & 15);
         const uint32_t q = align + o_rel;       // the value's place in the image
+        // the first twelve suffix bytes of every value, in flight while the inherited bytes are looked up
+        uint32_t w_first[3];
+#pragma unroll
+        for (uint32_t u = 0; u < 3; u++) w_first[u] = 4 * u < s ? data_u32(data, (uint64_t)s_at + 4 * u, data_total) : 0u;
 
         // ---- what the block inherits: bytes [0, need) of the value before it ----
         const uint32_t need = lane_u32(p, 0);
@@ -914,15 +955,20 @@ __global__ __launch_bounds__(WT) void dba_expand_kernel(const DevPage* __restric
             uint64_t cur = blk;    // among the blocks before `cur`
             while (r > 0 && cur > 0) {
                 const bool have = (uint64_t)lane < cur;
-                const uint64_t bi = have ? cur - 1 - lane : 0;
-                const uint32_t bm = have ? bstat[3 * bi + 2] : 0xffffffffu;
+                uint32_t bm = bm0;
+                if (cur != blk) bm = have ? bstat[3 * (cur - 1 - lane) + 2] & ~DBIG : 0xffffffffu;
                 const unsigned long long hit = __ballot(have && bm < r);
                 if (hit == 0) { cur = cur > 64 ? cur - 64 : 0; continue; }
                 const uint32_t first = (uint32_t)__builtin_ctzll(hit);
                 const uint64_t b2 = cur - 1 - first;
                 // lanes take the values of that block last to first
-                const uint64_t kk = b2 * DBLK + (63 - lane);
-                const uint32_t pj = (uint32_t)prefix[kk], sj = (uint32_t)suffix[kk];
+                uint32_t pj = pj0, sj = sj0, next_s = base_s;
+                if (b2 + 1 != blk) {
+                    const uint64_t kk = b2 * DBLK + (63 - lane);
+                    pj = (uint32_t)prefix[kk];
+                    sj = (uint32_t)suffix[kk];
+                    next_s = bstat[3 * (b2 + 1)];
+                }
                 uint32_t incl = pj; // least prefix length among this value and the later ones
                 for (int d = 1; d < 64; d <<= 1) {
                     const uint32_t o = (uint32_t)__shfl_up((int)incl, d);
@@ -931,7 +977,7 @@ __global__ __launch_bounds__(WT) void dba_expand_kernel(const DevPage* __restric
                 uint32_t later = (uint32_t)__shfl_up((int)incl, 1);
                 if (lane == 0) later = 0xffffffffu;
                 const uint32_t rj = later < r ? later : r;   // the value supplies bytes [pj, rj)
-                const uint32_t sj_at = bstat[3 * (b2 + 1)] - wave_inclusive_scan<uint32_t>(sj);
+                const uint32_t sj_at = next_s - wave_inclusive_scan<uint32_t>(sj);
                 unsigned long long cm = __ballot(pj < rj);
                 while (cm) {
                     const uint32_t j = (uint32_t)__builtin_ctzll(cm);
@@ -946,7 +992,15 @@ __global__ __launch_bounds__(WT) void dba_expand_kernel(const DevPage* __restric
         }
 
         // ---- suffix bytes into their places in the image ----
-        for (uint32_t t = 0; __ballot(t < s) != 0; t += 4) {
+#pragma unroll
+        for (uint32_t u = 0; u < 3; u++) {
+            const uint32_t t = 4 * u;
+            if (t < s) {
+                const uint32_t n = s - t < 4 ? s - t : 4;
+                for (uint32_t e = 0; e < n; e++) img[q + p + t + e] = (uint8_t)(w_first[u] >> (8 * e));
+            }
+        }
+        for (uint32_t t = 12; __ballot(t < s) != 0; t += 4) {
             if (t < s) {
                 const uint32_t w = data_u32(data, (uint64_t)s_at + t, data_total);
                 const uint32_t n = s - t < 4 ? s - t : 4;
@@ -961,9 +1015,20 @@ __global__ __launch_bounds__(WT) void dba_expand_kernel(const DevPage* __restric
             const uint32_t o = (uint32_t)__shfl_xor((int)longest, d);
             longest = o > longest ? o : longest;
         }
-        for (uint32_t c = 0; 4 * c < longest; c++) {
+        // columns that lie below every value's prefix length hold the inherited bytes as they are
+        const uint32_t plain = wave_min_u32(valid ? p : 0xffffffffu) / 4;
+        for (uint32_t c = 0; c < plain; c++) {
+            const uint32_t cw = carry32[c];
+            if (valid) {
+                img[q + 4 * c] = (uint8_t)cw;
+                img[q + 4 * c + 1] = (uint8_t)(cw >> 8);
+                img[q + 4 * c + 2] = (uint8_t)(cw >> 16);
+                img[q + 4 * c + 3] = (uint8_t)(cw >> 24);
+            }
+        }
+        for (uint32_t c = plain; 4 * c < longest; c++) {
             uint32_t at = q + 4 * c;
-            at = at < DIMG + 32 ? at : DIMG + 32;
+            at = at < IMG + 32 ? at : IMG + 32;
             uint32_t v = lds_u32(img32, at);
             const int32_t rel = (int32_t)p - (int32_t)(4 * c); // bytes of this dword below the prefix length
             uint32_t m = rel <= 0 ? 0xffffffffu : (rel >= 4 ? 0u : 0xffffffffu << (8 * rel));
@@ -1064,9 +1129,18 @@ void launch_dba(const DevPage* pages, DevResult* results, const uint32_t* items,
                 hipStream_t stream) {
     if (n_items == 0) return;
     const uint64_t blocks = (max_values + DBLK - 1) / DBLK;
-    hipLaunchKernelGGL(dba_block_kernel, dim3(n_items, tile_slots(blocks, MT / 64)), dim3(MT), 0, stream, pages, results, items);
+    // enough workgroups to fill the chip several times over, not one per block: the workgroups of
+    // the instantiation a page does not use only look at its result and leave
+    auto slots = [&](uint64_t units, uint64_t want_groups) {
+        uint64_t per_page = std::max<uint64_t>(1, want_groups / n_items);
+        return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(units, 1), std::min<uint64_t>(per_page, 4096));
+    };
+    hipLaunchKernelGGL(dba_block_kernel, dim3(n_items, slots((blocks + 15) / 16, 4096)), dim3(MT), 0, stream, pages, results, items);
     hipLaunchKernelGGL(dba_plan_kernel, dim3(n_items), dim3(MT), 0, stream, pages, results, items);
-    hipLaunchKernelGGL(dba_expand_kernel, dim3(n_items, tile_slots(blocks, 1)), dim3(WT), 0, stream, pages, results, items);
+    hipLaunchKernelGGL((dba_expand_kernel<DIMG_SMALL, DCARRY_SMALL, 1>), dim3(n_items, slots(blocks, 32768)), dim3(WT), 0, stream, pages,
+                       results, items);
+    hipLaunchKernelGGL((dba_expand_kernel<DIMG, DCARRY, 2>), dim3(n_items, slots(blocks, 32768)), dim3(WT), 0, stream, pages, results,
+                       items);
     hipLaunchKernelGGL(dba_kernel, dim3(n_items), dim3(WT), 0, stream, pages, results, items);
 }
 
