@@ -171,6 +171,52 @@ int pqd_dict_lookup_device(pqd_ctx* ctx, const void* dict_dev, uint64_t dict_len
                            const int32_t* indexes_dev, uint64_t n, void* rows_dev, uint64_t stride,
                            int64_t* status_dev, void* hip_stream);
 
+/* ---- definition and repetition levels, device-resident ------------------ */
+
+/*
+ * What the reader does with the levels DecodeLevels produced, for callers that
+ * keep a column on the device: all pointers are device pointers, the kernels
+ * are enqueued on `hip_stream`, nothing is allocated.  `workspace_dev` is
+ * caller-owned scratch of at least pqd_levels_workspace_size(n) bytes, 8-byte
+ * aligned; calls that share a workspace must not overlap.
+ */
+uint64_t pqd_levels_workspace_size(uint64_t n_levels);
+
+/* countLevelsEqual (level.go:11-13): *count_dev = levels equal to `value`.
+ * countLevelsNotEqual (level.go:15-17) is n minus that: optionalPage.NumNulls
+ * (page_optional.go:32-34) with value = the maximum definition level,
+ * repeatedPage.NumRows (page_repeated.go:33) with value = 0, the null count of
+ * Column.decodeDataPageV1 (column.go:772). */
+int pqd_levels_count_equal_device(pqd_ctx* ctx, const uint8_t* levels_dev, uint64_t n, uint8_t value,
+                                  void* workspace_dev, uint64_t workspace_bytes, uint64_t* count_dev,
+                                  void* hip_stream);
+
+/* optionalPageValues.ReadValues (page_optional.go:72-117) for a whole page:
+ * slot i takes the next of the page's `n_values` values when
+ * def_levels[i] == max_definition_level and is null otherwise.
+ * dst[i*width .. +width) = that value, or zeros for a null slot;
+ * validity_dev (may be null) gets 1 or 0 per slot.
+ * offsets_mode != 0: `values_dev` holds the n_values + 1 uint32 offsets of a
+ * byte-array page (width must be 4) and dst gets n_slots + 1 offsets, null
+ * slots empty.
+ * info_dev[0] = slots with a value, info_dev[1] = PQD_OK, or
+ * PQD_ERR_UNEXPECTED_EOF when the levels ask for more values than the page has
+ * (the io.EOF of page_optional.go:95-99); the slots past the last value are then
+ * zero. */
+int pqd_optional_expand_device(pqd_ctx* ctx, const uint8_t* def_levels_dev, uint64_t n_slots,
+                               uint8_t max_definition_level, const void* values_dev, uint64_t n_values,
+                               uint32_t width, int32_t offsets_mode, void* dst_dev, uint8_t* validity_dev,
+                               void* workspace_dev, uint64_t workspace_bytes, int64_t* info_dev, void* hip_stream);
+
+/* The row search of repeatedPage.Slice (page_repeated.go:73-98) for every row
+ * at once: row_starts_dev[k] = index of the k-th repetition level equal to 0,
+ * and row_starts_dev[n_rows] = n.  info_dev[0] = n_rows (repeatedPage.NumRows),
+ * info_dev[1] = PQD_OK or PQD_ERR_DST_TOO_SMALL when n_rows + 1 > row_cap (the
+ * first row_cap entries are still written). */
+int pqd_repeated_row_starts_device(pqd_ctx* ctx, const uint8_t* rep_levels_dev, uint64_t n, uint64_t* row_starts_dev,
+                                   uint64_t row_cap, void* workspace_dev, uint64_t workspace_bytes, int64_t* info_dev,
+                                   void* hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -106,6 +106,10 @@ SYMBOLS = {
     "pqd_dict_destroy": (None, [_vp]),
     "pqd_dict_lookup": (_int, [_vp, _vp, _u64, _vp, _u64, _pi64]),
     "pqd_dict_lookup_device": (_int, [_vp, _vp, _u64, C.c_uint32, _vp, _u64, _vp, _u64, _vp, _vp]),
+    "pqd_levels_workspace_size": (_u64, [_u64]),
+    "pqd_levels_count_equal_device": (_int, [_vp, _vp, _u64, C.c_uint8, _vp, _u64, _vp, _vp]),
+    "pqd_optional_expand_device": (_int, [_vp, _vp, _u64, C.c_uint8, _vp, _u64, C.c_uint32, C.c_int32, _vp, _vp, _vp, _u64, _vp, _vp]),
+    "pqd_repeated_row_starts_device": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp]),
 }
 
 _lib = None

@@ -1,0 +1,314 @@
+// levels.hip -- what parquet-go does with decoded definition and repetition levels, on gfx950:
+//
+//   countLevelsEqual / countLevelsNotEqual         level.go:11-17
+//     (optionalPage.NumNulls page_optional.go:32-34, repeatedPage.NumRows page_repeated.go:33,
+//      Column.decodeDataPageV1 column.go:772)
+//   optionalPageValues.ReadValues                  page_optional.go:72-117
+//     slot i of an optional column takes the next value when its definition level is the
+//     maximum, and is null otherwise
+//   repeatedPage.Slice row search                  page_repeated.go:73-98
+//     row k starts at the k-th repetition level that is 0
+//
+// All three are a count of the levels equal to one value, per stretch of 2048 levels, an
+// exclusive sum over the stretches, and a pass over the stretches that knows where each one
+// starts.  The caller supplies the workspace for the per-stretch counts.
+#include "pqd_internal.h"
+
+namespace pqd {
+namespace {
+
+constexpr uint32_t LT = 256;          // threads per workgroup
+constexpr uint32_t STRETCH = 2048;    // levels per wavefront
+constexpr uint32_t PER_GROUP = STRETCH * (LT / 64);
+
+// Bytes of a dword equal to the bytes of `pattern` (the value in all four bytes).
+__device__ inline uint32_t equal_bytes(uint32_t x, uint32_t pattern) {
+    const uint32_t t = x ^ pattern;                                   // zero bytes where equal
+    const uint32_t y = ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t | 0x7f7f7f7fu); // 0x80 in every zero byte
+    return (uint32_t)__popc(y);
+}
+
+typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
+__device__ inline void store_pair(gptr<uint64_t> p, uint64_t a, uint64_t b) { u64x2 v = {a, b}; *(gptr<u64x2>)p = v; }
+__device__ inline void store_pair(gptr<uint32_t> p, uint32_t a, uint32_t b) { u32x2 v = {a, b}; *(gptr<u32x2>)p = v; }
+__device__ inline void store_pair(gptr<uint8_t> p, uint8_t a, uint8_t b) { *(gptr<uint16_t>)p = (uint16_t)(a | ((uint16_t)b << 8)); }
+
+// counts[w] = levels equal to `value` in stretch w.
+__global__ __launch_bounds__(LT) void levels_count_kernel(const uint8_t* __restrict__ levels_, uint64_t n, uint32_t value,
+                                                          uint64_t n_stretches, uint64_t* __restrict__ counts_) {
+    gptr<const uint8_t> levels = as_global(levels_);
+    gptr<uint64_t> counts = as_global(counts_);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t pattern = value * 0x01010101u;
+    for (uint64_t w = (uint64_t)blockIdx.x * (LT / 64) + wave; w < n_stretches; w += (uint64_t)gridDim.x * (LT / 64)) {
+        const uint64_t at = w * STRETCH;
+        uint32_t c = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < STRETCH / (64 * 16); u++) {
+            const uint64_t b = at + (uint64_t)(u * 64 + lane) * 16;
+            if (b + 16 <= n && ((uintptr_t)(levels_ + b) & 3) == 0) {
+                const u32x4_a4 v = *(gptr<const u32x4_a4>)(levels + b);
+                c += equal_bytes(v.x, pattern) + equal_bytes(v.y, pattern) + equal_bytes(v.z, pattern) + equal_bytes(v.w, pattern);
+            } else {
+                for (uint32_t e = 0; e < 16 && b + e < n; e++) c += levels[b + e] == value ? 1u : 0u;
+            }
+        }
+        const uint32_t total = lane_u32(wave_inclusive_scan<uint32_t>(c), 63);
+        if (lane == 0) counts[w] = total;
+    }
+}
+
+// One workgroup: counts become exclusive sums in place, the total goes to counts[n_stretches]
+// and, when asked for, to `total_out`.
+__global__ __launch_bounds__(1024) void levels_scan_kernel(uint64_t* __restrict__ counts_, uint64_t n_stretches,
+                                                           uint64_t* __restrict__ total_out) {
+    __shared__ uint64_t wsum[16];
+    gptr<uint64_t> counts = as_global(counts_);
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint64_t carry = 0;
+    for (uint64_t base = 0; base < n_stretches; base += 1024 * 4) {
+        const uint64_t k = base + (uint64_t)tid * 4;
+        uint64_t v[4];
+        for (uint32_t e = 0; e < 4; e++) v[e] = k + e < n_stretches ? counts[k + e] : 0;
+        const uint64_t mine = v[0] + v[1] + v[2] + v[3];
+        const uint64_t x = wave_inclusive_scan<uint64_t>(mine);
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint64_t before = carry, all = 0;
+        for (uint32_t w = 0; w < 16; w++) {
+            if (w < wave) before += wsum[w];
+            all += wsum[w];
+        }
+        uint64_t o = before + x - mine;
+        for (uint32_t e = 0; e < 4; e++)
+            if (k + e < n_stretches) { counts[k + e] = o; o += v[e]; }
+        carry += all;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        counts[n_stretches] = carry;
+        if (total_out != nullptr) *as_global(total_out) = carry;
+    }
+}
+
+// page_optional.go:72-117 for fixed-width values.  A wavefront takes a stretch 128 slots at a
+// time, two neighbouring slots per lane: the place of a slot's value among the values is the
+// stretch's start plus the present slots before it (two ballots and mbcnt), the values are
+// read where they lie (neighbouring lanes read neighbouring values) and written 2 * W bytes
+// per lane.  Slots without a value are zero.  OFFSETS: the values are the n_values + 1
+// offsets of a byte-array page and every slot, present or not, takes the offset at its place,
+// so that null slots come out empty; dst then has n_slots + 1 entries.
+template <typename T, bool OFFSETS>
+__global__ __launch_bounds__(LT) void optional_expand_kernel(const uint8_t* __restrict__ def_, uint64_t n_slots, uint32_t max_def,
+                                                             const T* __restrict__ values_, uint64_t n_values, T* __restrict__ dst_,
+                                                             uint8_t* __restrict__ validity_, const uint64_t* __restrict__ starts_,
+                                                             uint64_t n_stretches, int64_t* __restrict__ info_) {
+    gptr<const uint8_t> def = as_global(def_);
+    gptr<const T> values = as_global(values_);
+    gptr<T> dst = as_global(dst_);
+    gptr<uint8_t> validity = as_global(validity_);
+    gptr<const uint64_t> starts = as_global(starts_);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint64_t present = starts[n_stretches];
+        gptr<int64_t> info = as_global(info_);
+        info[0] = (int64_t)present;
+        // more present slots than values: the page under the levels ran out (page_optional.go:95-99)
+        info[1] = present > n_values ? PQD_ERR_UNEXPECTED_EOF : PQD_OK;
+        if (OFFSETS) dst[n_slots] = values[present < n_values ? present : n_values];
+    }
+    for (uint64_t w = (uint64_t)blockIdx.x * (LT / 64) + wave; w < n_stretches; w += (uint64_t)gridDim.x * (LT / 64)) {
+        uint64_t base = starts[w];
+        const uint64_t at = w * STRETCH;
+        constexpr uint32_t STEPS = STRETCH / 128;
+        uint32_t lv[STEPS];
+#pragma unroll
+        for (uint32_t u = 0; u < STEPS; u++) {
+            const uint64_t s0 = at + u * 128 + 2 * lane;
+            uint32_t a = s0 < n_slots ? def[s0] : 0xffffffffu, b = s0 + 1 < n_slots ? def[s0 + 1] : 0xffffffffu;
+            lv[u] = (a == max_def ? 1u : 0u) | (b == max_def ? 2u : 0u) | (s0 < n_slots ? 4u : 0u) | (s0 + 1 < n_slots ? 8u : 0u);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < STEPS; u++) {
+            const uint64_t s0 = at + u * 128 + 2 * lane;
+            const bool p0 = lv[u] & 1, p1 = lv[u] & 2, in0 = lv[u] & 4, in1 = lv[u] & 8;
+            const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1);
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0)) +
+                                   __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0));
+            const uint64_t r0 = base + below, r1 = r0 + (p0 ? 1 : 0);
+            T v0 = T(), v1 = T();
+            if (OFFSETS) {
+                if (in0) v0 = values[r0 < n_values ? r0 : n_values];
+                if (in1) v1 = values[r1 < n_values ? r1 : n_values];
+            } else {
+                if (p0 && r0 < n_values) v0 = values[r0];
+                if (p1 && r1 < n_values) v1 = values[r1];
+            }
+            if (in1 && ((uintptr_t)(dst_ + s0) & (2 * sizeof(T) - 1)) == 0) {
+                store_pair(dst + s0, v0, v1);
+            } else {
+                if (in0) dst[s0] = v0;
+                if (in1) dst[s0 + 1] = v1;
+            }
+            if (validity_ != nullptr) {
+                if (in1 && ((uintptr_t)(validity_ + s0) & 1) == 0) *(gptr<uint16_t>)(validity + s0) = (uint16_t)((p0 ? 1u : 0u) | (p1 ? 0x100u : 0u));
+                else {
+                    if (in0) validity[s0] = p0 ? 1 : 0;
+                    if (in1) validity[s0 + 1] = p1 ? 1 : 0;
+                }
+            }
+            base += (uint64_t)__popcll(b0) + (uint64_t)__popcll(b1);
+        }
+    }
+}
+
+// The same for values of any width: a lane per slot, bytes copied one at a time.
+__global__ __launch_bounds__(LT) void optional_expand_bytes_kernel(const uint8_t* __restrict__ def_, uint64_t n_slots, uint32_t max_def,
+                                                                   const uint8_t* __restrict__ values_, uint64_t n_values, uint32_t width,
+                                                                   uint8_t* __restrict__ dst_, uint8_t* __restrict__ validity_,
+                                                                   const uint64_t* __restrict__ starts_, uint64_t n_stretches,
+                                                                   int64_t* __restrict__ info_) {
+    gptr<const uint8_t> def = as_global(def_);
+    gptr<const uint8_t> values = as_global(values_);
+    gptr<uint8_t> dst = as_global(dst_);
+    gptr<uint8_t> validity = as_global(validity_);
+    gptr<const uint64_t> starts = as_global(starts_);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint64_t present = starts[n_stretches];
+        gptr<int64_t> info = as_global(info_);
+        info[0] = (int64_t)present;
+        info[1] = present > n_values ? PQD_ERR_UNEXPECTED_EOF : PQD_OK;
+    }
+    for (uint64_t w = (uint64_t)blockIdx.x * (LT / 64) + wave; w < n_stretches; w += (uint64_t)gridDim.x * (LT / 64)) {
+        uint64_t base = starts[w];
+        for (uint32_t u = 0; u < STRETCH / 64; u++) {
+            const uint64_t s0 = w * STRETCH + u * 64 + lane;
+            const bool in = s0 < n_slots;
+            const bool p = in && def[s0] == max_def;
+            const unsigned long long b = __ballot(p);
+            const uint64_t r = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+            if (in) {
+                const bool have = p && r < n_values;
+                for (uint32_t e = 0; e < width; e++) dst[s0 * width + e] = have ? values[r * width + e] : (uint8_t)0;
+                if (validity_ != nullptr) validity[s0] = p ? 1 : 0;
+            }
+            base += (uint64_t)__popcll(b);
+        }
+    }
+}
+
+// page_repeated.go:73-98: row_starts[k] = index of the k-th repetition level equal to 0.
+__global__ __launch_bounds__(LT) void row_starts_kernel(const uint8_t* __restrict__ rep_, uint64_t n, uint64_t* __restrict__ rows_,
+                                                        uint64_t row_cap, const uint64_t* __restrict__ starts_, uint64_t n_stretches,
+                                                        int64_t* __restrict__ info_) {
+    gptr<const uint8_t> rep = as_global(rep_);
+    gptr<uint64_t> rows = as_global(rows_);
+    gptr<const uint64_t> starts = as_global(starts_);
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint64_t n_rows = starts[n_stretches];
+        gptr<int64_t> info = as_global(info_);
+        info[0] = (int64_t)n_rows;
+        info[1] = n_rows + 1 > row_cap ? PQD_ERR_DST_TOO_SMALL : PQD_OK;
+        if (n_rows < row_cap) rows[n_rows] = n; // the end of the last row
+    }
+    for (uint64_t w = (uint64_t)blockIdx.x * (LT / 64) + wave; w < n_stretches; w += (uint64_t)gridDim.x * (LT / 64)) {
+        uint64_t base = starts[w];
+        for (uint32_t u = 0; u < STRETCH / 64; u++) {
+            const uint64_t s0 = w * STRETCH + u * 64 + lane;
+            const bool z = s0 < n && rep[s0] == 0;
+            const unsigned long long b = __ballot(z);
+            const uint64_t r = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+            if (z && r < row_cap) rows[r] = s0;
+            base += (uint64_t)__popcll(b);
+        }
+    }
+}
+
+uint64_t stretches_of(uint64_t n) { return (n + STRETCH - 1) / STRETCH; }
+
+uint32_t groups_for(uint64_t n_stretches) {
+    const uint64_t g = (n_stretches + LT / 64 - 1) / (LT / 64);
+    return (uint32_t)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
+}
+
+bool count_and_scan(const uint8_t* levels, uint64_t n, uint8_t value, void* workspace, uint64_t workspace_bytes, uint64_t* total,
+                    hipStream_t s) {
+    const uint64_t ns = stretches_of(n);
+    if (workspace == nullptr || workspace_bytes < (ns + 1) * sizeof(uint64_t) || ((uintptr_t)workspace & 7) != 0) return false;
+    uint64_t* counts = static_cast<uint64_t*>(workspace);
+    if (ns > 0) hipLaunchKernelGGL(levels_count_kernel, dim3(groups_for(ns)), dim3(LT), 0, s, levels, n, (uint32_t)value, ns, counts);
+    hipLaunchKernelGGL(levels_scan_kernel, dim3(1), dim3(1024), 0, s, counts, ns, total);
+    return true;
+}
+
+} // namespace
+} // namespace pqd
+
+using namespace pqd;
+
+extern "C" {
+
+uint64_t pqd_levels_workspace_size(uint64_t n_levels) { return (stretches_of(n_levels) + 1) * sizeof(uint64_t); }
+
+int pqd_levels_count_equal_device(pqd_ctx* ctx, const uint8_t* levels_dev, uint64_t n, uint8_t value, void* workspace_dev,
+                                  uint64_t workspace_bytes, uint64_t* count_dev, void* hip_stream) {
+    if (ctx == nullptr || count_dev == nullptr || (levels_dev == nullptr && n > 0)) return PQD_ERR_INVALID_ARGUMENT;
+    if (!count_and_scan(levels_dev, n, value, workspace_dev, workspace_bytes, count_dev, static_cast<hipStream_t>(hip_stream)))
+        return PQD_ERR_INVALID_ARGUMENT;
+    return hipGetLastError() == hipSuccess ? PQD_OK : PQD_ERR_DEVICE;
+}
+
+int pqd_optional_expand_device(pqd_ctx* ctx, const uint8_t* def_levels_dev, uint64_t n_slots, uint8_t max_definition_level,
+                               const void* values_dev, uint64_t n_values, uint32_t width, int32_t offsets_mode, void* dst_dev,
+                               uint8_t* validity_dev, void* workspace_dev, uint64_t workspace_bytes, int64_t* info_dev,
+                               void* hip_stream) {
+    if (ctx == nullptr || info_dev == nullptr || width == 0 || (def_levels_dev == nullptr && n_slots > 0) ||
+        (dst_dev == nullptr && n_slots > 0) || (values_dev == nullptr && n_values > 0))
+        return PQD_ERR_INVALID_ARGUMENT;
+    if (offsets_mode && (width != 4 || values_dev == nullptr || dst_dev == nullptr)) return PQD_ERR_INVALID_ARGUMENT;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (!count_and_scan(def_levels_dev, n_slots, max_definition_level, workspace_dev, workspace_bytes, nullptr, s))
+        return PQD_ERR_INVALID_ARGUMENT;
+    const uint64_t ns = stretches_of(n_slots);
+    const uint64_t* starts = static_cast<const uint64_t*>(workspace_dev);
+    const uint32_t groups = groups_for(ns);
+    const uint32_t md = max_definition_level;
+    const bool aligned = ((uintptr_t)values_dev % width) == 0 && ((uintptr_t)dst_dev % width) == 0;
+    if (offsets_mode)
+        hipLaunchKernelGGL((optional_expand_kernel<uint32_t, true>), dim3(groups), dim3(LT), 0, s, def_levels_dev, n_slots, md,
+                           static_cast<const uint32_t*>(values_dev), n_values, static_cast<uint32_t*>(dst_dev), validity_dev, starts, ns,
+                           info_dev);
+    else if (width == 8 && aligned)
+        hipLaunchKernelGGL((optional_expand_kernel<uint64_t, false>), dim3(groups), dim3(LT), 0, s, def_levels_dev, n_slots, md,
+                           static_cast<const uint64_t*>(values_dev), n_values, static_cast<uint64_t*>(dst_dev), validity_dev, starts, ns,
+                           info_dev);
+    else if (width == 4 && aligned)
+        hipLaunchKernelGGL((optional_expand_kernel<uint32_t, false>), dim3(groups), dim3(LT), 0, s, def_levels_dev, n_slots, md,
+                           static_cast<const uint32_t*>(values_dev), n_values, static_cast<uint32_t*>(dst_dev), validity_dev, starts, ns,
+                           info_dev);
+    else if (width == 1)
+        hipLaunchKernelGGL((optional_expand_kernel<uint8_t, false>), dim3(groups), dim3(LT), 0, s, def_levels_dev, n_slots, md,
+                           static_cast<const uint8_t*>(values_dev), n_values, static_cast<uint8_t*>(dst_dev), validity_dev, starts, ns,
+                           info_dev);
+    else
+        hipLaunchKernelGGL(optional_expand_bytes_kernel, dim3(groups), dim3(LT), 0, s, def_levels_dev, n_slots, md,
+                           static_cast<const uint8_t*>(values_dev), n_values, width, static_cast<uint8_t*>(dst_dev), validity_dev, starts,
+                           ns, info_dev);
+    return hipGetLastError() == hipSuccess ? PQD_OK : PQD_ERR_DEVICE;
+}
+
+int pqd_repeated_row_starts_device(pqd_ctx* ctx, const uint8_t* rep_levels_dev, uint64_t n, uint64_t* row_starts_dev, uint64_t row_cap,
+                                   void* workspace_dev, uint64_t workspace_bytes, int64_t* info_dev, void* hip_stream) {
+    if (ctx == nullptr || info_dev == nullptr || (rep_levels_dev == nullptr && n > 0) || (row_starts_dev == nullptr && row_cap > 0))
+        return PQD_ERR_INVALID_ARGUMENT;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    if (!count_and_scan(rep_levels_dev, n, 0, workspace_dev, workspace_bytes, nullptr, s)) return PQD_ERR_INVALID_ARGUMENT;
+    const uint64_t ns = stretches_of(n);
+    hipLaunchKernelGGL(row_starts_kernel, dim3(groups_for(ns)), dim3(LT), 0, s, rep_levels_dev, n, row_starts_dev, row_cap,
+                       static_cast<const uint64_t*>(workspace_dev), ns, info_dev);
+    return hipGetLastError() == hipSuccess ? PQD_OK : PQD_ERR_DEVICE;
+}
+
+} // extern "C"
