@@ -217,6 +217,82 @@ int pqd_repeated_row_starts_device(pqd_ctx* ctx, const uint8_t* rep_levels_dev, 
                                    uint64_t row_cap, void* workspace_dev, uint64_t workspace_bytes, int64_t* info_dev,
                                    void* hip_stream);
 
+/* ---- column chunks: page headers and the parts of a page (host) --------- */
+
+/* format.PageType (format/parquet.go) */
+enum { PQD_PAGE_DATA = 0, PQD_PAGE_INDEX = 1, PQD_PAGE_DICTIONARY = 2, PQD_PAGE_DATA_V2 = 3 };
+
+/* format.PageHeader with the header of its page type folded in
+ * (format/parquet.go:752-821, 910-953). */
+typedef struct pqd_page_header {
+    int32_t  type;                         /* PQD_PAGE_* */
+    int32_t  uncompressed_page_size;
+    int32_t  compressed_page_size;
+    int32_t  has_crc;
+    int32_t  crc;
+    int32_t  num_values;                   /* of the data or dictionary page */
+    int32_t  encoding;                     /* of the values */
+    int32_t  definition_level_encoding;    /* data page v1; RLE for v2 */
+    int32_t  repetition_level_encoding;
+    int32_t  num_nulls;                    /* v2, otherwise -1 */
+    int32_t  num_rows;                     /* v2, otherwise -1 */
+    int32_t  definition_levels_byte_length; /* v2 */
+    int32_t  repetition_levels_byte_length; /* v2 */
+    int32_t  is_compressed;                /* v2 flag; 1 when absent */
+    int32_t  is_sorted;                    /* dictionary page */
+    int32_t  reserved;
+    uint64_t header_offset;                /* of the thrift header in the chunk */
+    uint64_t data_offset;                  /* the page is chunk[data_offset .. + compressed_page_size) */
+} pqd_page_header;
+
+/* The header loop of FilePages.ReadPage (file.go:1193-1259) over a column
+ * chunk held in host memory: every page header, decoded with the thrift
+ * compact protocol (encoding/thrift/compact.go:132-170, 196-245) and checked as
+ * validatePageHeader does (file.go:1414-1445).  `num_values` >= 0 ends the walk
+ * once the data pages seen hold that many values (ColumnMetaData.num_values),
+ * -1 walks to the end of the bytes.  Writes up to `cap` headers and the number
+ * found.  PQD_ERR_DST_TOO_SMALL when there are more than `cap`;
+ * PQD_ERR_UNEXPECTED_EOF for a header or page cut short,
+ * PQD_ERR_INVALID_ARGUMENT for negative sizes or counts (ErrCorrupted in the
+ * reference); *status_arg = offset of the failing header. */
+int pqd_chunk_scan_pages(const uint8_t* chunk, uint64_t chunk_len, int64_t num_values, pqd_page_header* out,
+                         uint64_t cap, uint64_t* n_pages, int64_t* status_arg);
+
+/* What Column.decodeDataPage needs to know about the column (column.go:845-911). */
+typedef struct pqd_column_info {
+    int32_t kind;                   /* pqd_kind of the values */
+    int32_t type_length;            /* FIXED_LEN_BYTE_ARRAY */
+    int32_t max_definition_level;
+    int32_t max_repetition_level;
+} pqd_column_info;
+
+enum { PQD_PART_REPETITION_LEVELS = 0, PQD_PART_DEFINITION_LEVELS = 1, PQD_PART_VALUES = 2, PQD_PART_DICTIONARY = 3 };
+
+typedef struct pqd_page_part {
+    uint64_t page;        /* index into the headers */
+    int32_t  role;        /* PQD_PART_* */
+    int32_t  reserved;
+    uint64_t src_offset;  /* of the part in the chunk */
+} pqd_page_part;
+
+/* How Column.decodeDataPageV1 / decodeDataPageV2 / decodeDictionary
+ * (column.go:733-843, 963-993) cut the pages of an UNCOMPRESSED chunk into
+ * work items: per data page the repetition levels (if the column has any), the
+ * definition levels, the values; per dictionary page its values.  Fills
+ * src (= chunk_dev + offset), src_len, encoding, kind, bit_width and
+ * num_values of each item: level widths are bits.Len8(max level)
+ * (encoding.go:124-134), PLAIN_DICTIONARY becomes RLE_DICTIONARY in data pages
+ * and PLAIN in dictionary pages (column.go:850-857, 976-979), the values of a
+ * v2 page are num_values - num_nulls (column.go:841), those of a v1 page with
+ * definition levels are not known before the levels are counted (num_values
+ * = -1).  The caller sets dst, offsets and dict; a dictionary-encoded page decoded
+ * without `dict` yields its indexes and needs kind = PQD_KIND_INT32
+ * (indexedPageType.Decode, dictionary.go:217-219).  `chunk` is the host copy
+ * (the level lengths of v1 pages are read from it, column.go:913-924). */
+int pqd_chunk_plan_pages(const pqd_page_header* headers, uint64_t n_headers, const uint8_t* chunk, uint64_t chunk_len,
+                         const void* chunk_dev, const pqd_column_info* column, pqd_page* items, pqd_page_part* parts,
+                         uint64_t cap, uint64_t* n_items, int64_t* status_arg);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,6 +78,26 @@ class Page(C.Structure):
     ]
 
 
+class PageHeader(C.Structure):
+    """struct pqd_page_header"""
+    _fields_ = [(n, C.c_int32) for n in (
+        "type", "uncompressed_page_size", "compressed_page_size", "has_crc", "crc", "num_values", "encoding",
+        "definition_level_encoding", "repetition_level_encoding", "num_nulls", "num_rows", "definition_levels_byte_length",
+        "repetition_levels_byte_length", "is_compressed", "is_sorted", "reserved")] + [
+        ("header_offset", C.c_uint64), ("data_offset", C.c_uint64)]
+
+
+class ColumnInfo(C.Structure):
+    """struct pqd_column_info"""
+    _fields_ = [("kind", C.c_int32), ("type_length", C.c_int32), ("max_definition_level", C.c_int32),
+                ("max_repetition_level", C.c_int32)]
+
+
+class PagePart(C.Structure):
+    """struct pqd_page_part"""
+    _fields_ = [("page", C.c_uint64), ("role", C.c_int32), ("reserved", C.c_int32), ("src_offset", C.c_uint64)]
+
+
 # every symbol include/pqd.h declares: name -> (restype, argtypes)
 _vp, _u64, _i64, _int = C.c_void_p, C.c_uint64, C.c_int64, C.c_int
 _pu64, _pi64 = C.POINTER(C.c_uint64), C.POINTER(C.c_int64)
@@ -110,6 +130,9 @@ SYMBOLS = {
     "pqd_levels_count_equal_device": (_int, [_vp, _vp, _u64, C.c_uint8, _vp, _u64, _vp, _vp]),
     "pqd_optional_expand_device": (_int, [_vp, _vp, _u64, C.c_uint8, _vp, _u64, C.c_uint32, C.c_int32, _vp, _vp, _vp, _u64, _vp, _vp]),
     "pqd_repeated_row_starts_device": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp]),
+    "pqd_chunk_scan_pages": (_int, [_vp, _u64, _i64, C.POINTER(PageHeader), _u64, _pu64, _pi64]),
+    "pqd_chunk_plan_pages": (_int, [C.POINTER(PageHeader), _u64, _vp, _u64, _vp, C.POINTER(ColumnInfo), C.POINTER(Page),
+                                    C.POINTER(PagePart), _u64, _pu64, _pi64]),
 }
 
 _lib = None

@@ -19,7 +19,6 @@ namespace {
 
 constexpr uint32_t LT = 256;          // threads per workgroup
 constexpr uint32_t STRETCH = 2048;    // levels per wavefront
-constexpr uint32_t PER_GROUP = STRETCH * (LT / 64);
 
 // Bytes of a dword equal to the bytes of `pattern` (the value in all four bytes).
 __device__ inline uint32_t equal_bytes(uint32_t x, uint32_t pattern) {
