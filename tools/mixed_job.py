@@ -2,7 +2,8 @@
 measured shapes -- RLE_DICTIONARY int64 (64 Ki-entry dictionary), DELTA_BINARY_PACKED int64
 timestamps, RLE definition levels, BYTE_STREAM_SPLIT doubles -- 1 Mi values per chunk in pages
 of 131072 values.  Decoded once with a batch per row group (what a reader that goes row group
-by row group submits) and once with all row groups in one batch.  Row group g belongs to rank
+by row group submits; on one stream, and dealt to eight streams) and once with all row groups
+in one batch.  Row group g belongs to rank
 g mod N in a multi-GPU run; this tool measures one rank's share.
 
     python tools/mixed_job.py [row_groups] [columns]      (defaults 16, 16)
@@ -107,10 +108,28 @@ def main():
         def launch(self, s):
             one.launch(s)
 
+    side = [torch.cuda.Stream(device=M.DEV) for _ in range(8)]
+
+    class PerGroupStreams:
+        """The same batches, dealt round robin to eight streams that fork from the caller's and join it again."""
+        def launch(self, s):
+            main = torch.cuda.ExternalStream(s, device=M.DEV)
+            fork = torch.cuda.Event()
+            fork.record(main)
+            for st in side[: len(per_group)]:
+                st.wait_event(fork)
+            for i, b in enumerate(per_group):
+                b.launch(side[i % len(side)].cuda_stream)
+            for st in side[: len(per_group)]:
+                done = torch.cuda.Event()
+                done.record(st)
+                main.wait_event(done)
+
     n_pages = row_groups * columns * PAGES_PER_CHUNK
     print(f"mixed job: {row_groups} row groups x {columns} column chunks x {PAGES_PER_CHUNK} pages of {PAGE} values "
           f"({n_pages} pages, {out_bytes / 1e9:.2f} GB decoded, {enc_b / 1e9:.2f} GB encoded)")
-    for name, wl in (("a batch per row group", PerGroup()), ("all row groups in one batch", One())):
+    for name, wl in (("a batch per row group", PerGroup()), ("a batch per row group, 8 streams", PerGroupStreams()),
+                     ("all row groups in one batch", One())):
         wall, kms = bench.time_steps(M.S, torch, wl, stream, 20, 3, None)
         t = float(np.mean(kms)) / 1e3
         print(f"  {name:30s} {t * 1e6:9.1f} us  decoded {out_bytes / t / 1e9:8.1f} GB/s  algorithmic {(out_bytes + enc_b) / t / 1e9:8.1f} GB/s  "
