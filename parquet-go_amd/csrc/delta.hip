@@ -25,7 +25,8 @@ constexpr uint32_t RING_BYTES = 16384;
 constexpr uint32_t RING_MASK = RING_BYTES - 1;
 constexpr uint32_t RING_DW_MASK = RING_BYTES / 4 - 1;
 constexpr uint32_t CHUNK = DT * 16;           // bytes one fill step brings in
-constexpr uint32_t LOOK = 3 * CHUNK;          // bytes kept ahead of the tile start
+constexpr uint32_t LOOK = 3 * CHUNK;          // bytes the prefetch brings the ring up to, ahead of the tile start
+constexpr uint32_t LOOK_MIN = 2 * CHUNK;      // bytes ahead of the tile start that every tile finds resident
 constexpr int MAX_SLOTS = 40;                 // miniblocks a tile can touch (1024/32 + partials)
 constexpr int BW_CACHE = 64;                  // bit widths of one block kept in LDS
 
@@ -380,11 +381,11 @@ __device__ inline int ring_uvarint32(const uint8_t* ring8, uint32_t pos, uint32_
     }
 }
 
-// Synchronous top-up of the ring: chunks c_next .. lo/CHUNK + 3.
+// Synchronous top-up of the ring: chunks c_next .. lo/CHUNK + LOOK_MIN/CHUNK.
 __device__ inline void ring_fill32(uint32_t* ring, gptr<const uint8_t> base, uint32_t end, uint32_t lo, uint32_t& c_next) {
     const uint32_t c_lo = lo / CHUNK;
     if (c_next < c_lo) c_next = c_lo;
-    const uint32_t c_stop = c_lo + LOOK / CHUNK;
+    const uint32_t c_stop = c_lo + LOOK_MIN / CHUNK;
     while (c_next <= c_stop) {
         const uint32_t v = c_next * CHUNK + threadIdx.x * 16u;
         const uint32_t vs = v < end ? v : 0u; // always a readable address; ring_put discards what lies past the end
@@ -518,7 +519,7 @@ void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict_
                 const uint32_t w_nb_tile = w_bs ? TILE >> w_blk_shift : 1;
                 const uint32_t w_total = (uint32_t)sh.ctl.total;
                 const uint32_t w_n_deltas = w_total > 0 ? w_total - 1 : 0;
-                const uint32_t win_hi = (lo / CHUNK + LOOK / CHUNK + 1) * CHUNK; // resident bytes end here
+                const uint32_t win_hi = c_next * CHUNK; // resident bytes end here
                 const uint32_t rem = w_n_deltas - done;
                 const uint32_t blocks_left = (rem + w_bs - 1) >> w_blk_shift;
                 const uint32_t target = blocks_left < TBL_TILES * w_nb_tile ? blocks_left : TBL_TILES * w_nb_tile;
@@ -690,6 +691,21 @@ void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict_
             }
         }
 
+        {
+            // a tile that reaches past what is resident (wide miniblocks after narrow ones): bring the rest in now
+            const uint32_t tile_end = sh.fc.tile_lo[tbl_next + 1];
+            if (tile_end > c_next * CHUNK) {
+                const uint32_t c_last = (tile_end - 1) / CHUNK;
+                while (c_next <= c_last) {
+                    const uint32_t v = c_next * CHUNK + threadIdx.x * 16u;
+                    const uint32_t vs = v < end ? v : 0u;
+                    const u32x4 w = *(gptr<const u32x4>)(base + vs);
+                    ring_put(sh.ring, v, end, w);
+                    c_next++;
+                }
+                lds_barrier();
+            }
+        }
         // The thread number, opaque to the optimiser from here on: whatever the tile derives from it is
         // computed again per tile (a few instructions) instead of being kept in registers across the walk.
         uint32_t tq = tid;
@@ -718,6 +734,10 @@ void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict_
         const uint32_t lo_next = sh.fc.tile_lo[tbl_next + 1];
         const uint32_t c_want = lo_next / CHUNK + LOOK / CHUNK; // last chunk the next tile wants
         pf_n = c_next > c_want ? 0u : (c_want + 1 - c_next > 2 ? 2u : c_want + 1 - c_next);
+        // Fewer, larger reads: while tiles are small nothing is fetched as long as the ring is still
+        // LOOK_MIN ahead of the next tile, and then two chunks at once.  A read inside a saturated
+        // stream of stores is dear whatever its size, so 8 KB every few tiles beats 4 KB twice as often.
+        if (c_next > lo_next / CHUNK + LOOK_MIN / CHUNK && lo_next - lo <= 3072) pf_n = 0;
         pf_v = c_next * CHUNK + tq * 16u;
         {
             const uint32_t pv1 = pf_v + CHUNK;
