@@ -420,3 +420,31 @@ def test_delta_byte_array_block_by_block_errors():
         want = O.dba_decode(enc)
         assert want.status != 0, k
         _same_byte_array(out, want, f"error case {k}")
+
+
+def test_delta_byte_array_random_length_streams():
+    # prefix / suffix length streams drawn at random (not derived from strings): every prefix
+    # length that the value before allows, many empty suffixes, lengths around the block limits
+    P = pkg()
+    rng = np.random.default_rng(23)
+    encs = []
+    for trial in range(24):
+        n = int(rng.integers(1, 6000))
+        top = int(rng.choice([3, 17, 70, 130, 300]))          # longest suffix
+        p_keep = float(rng.choice([0.0, 0.5, 0.9, 0.99]))     # how often a value keeps (part of) the one before
+        prefix, suffix, last = np.zeros(n, np.int32), np.zeros(n, np.int32), 0
+        for k in range(n):
+            p = int(rng.integers(0, last + 1)) if rng.random() < p_keep else 0
+            if rng.random() < 0.3:
+                p = last                                        # the whole value before
+            s = 0 if rng.random() < 0.2 else int(rng.integers(0, top + 1))
+            if p + s > 1200:
+                s = max(0, 1200 - p)
+            prefix[k], suffix[k], last = p, s, p + s
+        data = bytes(rng.integers(0, 256, size=int(suffix.sum()), dtype=np.uint8))
+        encs.append(O.delta_encode_int32(prefix) + O.delta_encode_int32(suffix) + data)
+    outs = decode([spec(P.ENC.DELTA_BYTE_ARRAY, P.KIND.BYTE_ARRAY, e, misalign=k % 16) for k, e in enumerate(encs)])
+    for k, (enc, out) in enumerate(zip(encs, outs)):
+        want = O.dba_decode(enc)
+        assert want.status == 0, k
+        _same_byte_array(out, want, f"random streams {k}")
