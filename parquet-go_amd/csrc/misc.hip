@@ -250,13 +250,28 @@ __global__ __launch_bounds__(MT) void plain_fixed_kernel(const DevPage* __restri
 // ------------------------------------------------------ PLAIN byte arrays --
 
 constexpr int WT = 64;                   // the walkers below run one wavefront per page
-constexpr uint32_t PSTAGE = 8192;        // bytes of the page staged in LDS at a time
+
+// Hand-off through LDS inside a workgroup of ONE wavefront: the wave's LDS operations execute in
+// order, so all it takes is that the compiler keeps them in order and the earlier ones have
+// landed.  __syncthreads() would also wait for every outstanding global store of the wave
+// (vmcnt(0)), a microsecond or more per call once the stores are queued behind others.
+__device__ inline void wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+constexpr uint32_t PSTAGE = 16384;       // bytes of the page staged in LDS at a time
 constexpr uint32_t PBATCH = 64;          // values handled per round
 
-// Fills LDS bytes [0, n) from global memory: 16 bytes per lane and step, then the tail.
+// Fills LDS bytes [0, n) from global memory: 16 bytes per lane and step, eight steps' loads in
+// flight together (one wavefront has nobody to hide a load's latency behind), then the tail.
 __device__ inline void stage_fill(uint8_t* stage, gptr<const uint8_t> src, uint64_t n, uint32_t lane) {
     const uint64_t body = n / 16;
-    for (uint64_t c = lane; c < body; c += WT) {
+    uint64_t c0 = 0;
+    for (; c0 + 8 * WT <= body; c0 += 8 * WT) {
+        u32x4_a1 w[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) w[u] = *(gptr<const u32x4_a1>)(src + (c0 + u * WT + lane) * 16);
+#pragma unroll
+        for (uint32_t u = 0; u < 8; u++) *reinterpret_cast<u32x4*>(stage + (c0 + u * WT + lane) * 16) = w[u];
+    }
+    for (uint64_t c = c0 + lane; c < body; c += WT) {
         const u32x4_a1 w = *(gptr<const u32x4_a1>)(src + c * 16);
         *reinterpret_cast<u32x4*>(stage + c * 16) = w;
     }
@@ -273,25 +288,14 @@ __device__ inline uint32_t lds_u32(const uint32_t* stage32, uint32_t off) {
     return __builtin_amdgcn_alignbit(stage32[d + 1], stage32[d], (off & 3) * 8);
 }
 
-// Copies `len` bytes from LDS offset `pos` to global `dst`, four at a time: what one lane does
-// for its own value while the other lanes do theirs.
-__device__ inline void lane_copy(gptr<uint8_t> dst, const uint32_t* stage32, uint32_t pos, uint32_t len, uint32_t round) {
-    const uint32_t b = round * 4;
-    if (b + 4 <= len) {
-        *(gptr<u32_a1>)(dst + b) = lds_u32(stage32, pos + b);
-    } else if (b < len) {
-        const uint32_t w = lds_u32(stage32, pos + b);
-        for (uint32_t k = 0; b + k < len; k++) dst[b + k] = (uint8_t)(w >> (8 * k));
-    }
-}
-
 // plain.go:76-94: a walk over `u32 length | bytes` records.  Each record's position depends on
 // the one before, so the lengths are found speculatively: lane l guesses that record l starts
 // l * (4 + g) bytes after the first, g being the length of the record before, reads the length
 // it finds there, and the guess holds for every lane whose predecessors all measured g again
 // (equal lengths in a row -- ids, dates, fixed formats -- give 64 records per round, anything else
-// at least one).  Rounds fill a batch of 64 records out of an LDS copy of the page; then every
-// lane owns one record: offsets by a wave scan, bytes copied four at a time by all lanes at once.
+// at least one).  Rounds fill a batch of 64 records out of an LDS copy of 16 KB of the page, which
+// serves batch after batch until the next record is not wholly in it; then every lane owns one
+// record: offsets by a wave scan, bytes copied four at a time by all lanes at once.
 __global__ __launch_bounds__(WT) void plain_byte_array_kernel(const DevPage* __restrict__ pages,
                                                               DevResult* __restrict__ results,
                                                               const uint32_t* __restrict__ items) {
@@ -311,103 +315,126 @@ __global__ __launch_bounds__(WT) void plain_byte_array_kernel(const DevPage* __r
     int32_t status = PQD_OK;
     int64_t arg = 0;
     while (i < n && status == PQD_OK) {
-        // stage [i, i + PSTAGE)
+        // stage [i, i + PSTAGE); batches are taken out of it for as long as whole records are staged
         const uint32_t avail = n - i < PSTAGE ? (uint32_t)(n - i) : PSTAGE;
         stage_fill(stage, src + i, avail, lane);
-        __syncthreads();
+        wave_sync();
         const uint64_t left = n - i; // bytes from the start of the stage to the end of the page
-        uint32_t p = 0, cnt = 0;     // position in the stage, records in the batch
-        bool big = false;            // a record that does not fit the stage: handled on its own
-        while (cnt < PBATCH && p < left && status == PQD_OK) {
-            // ---- one speculative round ----
-            const uint64_t c64 = (uint64_t)p + (uint64_t)lane * (4ull + guess);
-            const bool inwin = c64 + 4 <= avail;                 // header staged
-            const uint32_t c = inwin ? (uint32_t)c64 : 0;
-            const uint32_t len = lds_u32(stage32, c);
-            // 0 fine, 1 truncated input (plain.ErrTooShort), 2 stop here: not (all) staged
-            uint32_t what = 0;
-            if (c64 >= left) what = 2;                           // past the last record
-            else if (left - c64 < 4) what = 1;
-            else if (!inwin) what = 2;
-            else if (len > n - 4 || len > left - c64 - 4) what = 1;
-            else if (c64 + 4 + len > avail) what = 2;
-            const unsigned long long same = __ballot(what == 0 && len == guess);
-            const uint32_t lead = same == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~same);
-            // lanes [0, lead) measured the guess again; lane `lead` sits at a true record start too
-            uint32_t valid = lead;
-            uint32_t stop_what = 2;
-            if (lead < 64) {
-                stop_what = lane_u32(what, lead);
-                if (stop_what == 0) valid = lead + 1;
-            }
-            if (valid > PBATCH - cnt) { valid = PBATCH - cnt; stop_what = 0; }
-            if (lane < valid) { v_pos[cnt + lane] = c + 4; v_len[cnt + lane] = len; }
-            if (valid > 0) {
-                const uint32_t l = valid - 1;
-                guess = lane_u32(len, l);
-                p = lane_u32(c, l) + 4 + guess;
-                cnt += valid;
-            }
-            if (valid == 0 || (valid <= lead && lead < 64 && stop_what != 0)) {
-                // the record after the valid ones cannot be taken this round
-                const uint32_t at = valid == 0 ? 0 : lead; // lane holding it (valid == lead here)
-                const uint32_t w = valid == 0 ? lane_u32(what, 0) : stop_what;
-                if (w == 1) { status = PQD_ERR_UNEXPECTED_EOF; arg = PQD_EOF_PLAIN_BYTE_ARRAY; }
-                else if (cnt == 0 && lane_u32((uint32_t)inwin, at) && lane_u32((uint32_t)(c64 < left), at)) {
-                    // its header is staged but its bytes are not, and nothing else is pending: take it alone
-                    if (lane == 0) { v_pos[0] = lane_u32(c, at) + 4; v_len[0] = lane_u32(len, at); }
-                    big = true;
-                    cnt = 1;
+        uint32_t p = 0;              // position in the stage
+        bool restage = false;
+        while (!restage && status == PQD_OK) {
+            uint32_t cnt = 0;        // records in the batch
+            bool big = false;        // a record that does not fit the stage: handled on its own
+            while (cnt < PBATCH && p < left && status == PQD_OK) {
+                // ---- one speculative round ----
+                const uint64_t c64 = (uint64_t)p + (uint64_t)lane * (4ull + guess);
+                const bool inwin = c64 + 4 <= avail;                 // header staged
+                const uint32_t c = inwin ? (uint32_t)c64 : 0;
+                const uint32_t len = lds_u32(stage32, c);
+                // 0 fine, 1 truncated input (plain.ErrTooShort), 2 stop here: not (all) staged
+                uint32_t what = 0;
+                if (c64 >= left) what = 2;                           // past the last record
+                else if (left - c64 < 4) what = 1;
+                else if (!inwin) what = 2;
+                else if (len > n - 4 || len > left - c64 - 4) what = 1;
+                else if (c64 + 4 + len > avail) what = 2;
+                const unsigned long long same = __ballot(what == 0 && len == guess);
+                const uint32_t lead = same == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~same);
+                // lanes [0, lead) measured the guess again; lane `lead` sits at a true record start too
+                uint32_t valid = lead;
+                uint32_t stop_what = 2;
+                if (lead < 64) {
+                    stop_what = lane_u32(what, lead);
+                    if (stop_what == 0) valid = lead + 1;
                 }
-                break;
+                if (valid > PBATCH - cnt) { valid = PBATCH - cnt; stop_what = 0; }
+                if (lane < valid) { v_pos[cnt + lane] = c + 4; v_len[cnt + lane] = len; }
+                if (valid > 0) {
+                    const uint32_t l = valid - 1;
+                    guess = lane_u32(len, l);
+                    p = lane_u32(c, l) + 4 + guess;
+                    cnt += valid;
+                }
+                if (valid == 0 || (valid <= lead && lead < 64 && stop_what != 0)) {
+                    // the record after the valid ones cannot be taken this round
+                    const uint32_t at = valid == 0 ? 0 : lead; // lane holding it (valid == lead here)
+                    const uint32_t w = valid == 0 ? lane_u32(what, 0) : stop_what;
+                    if (w == 1) { status = PQD_ERR_UNEXPECTED_EOF; arg = PQD_EOF_PLAIN_BYTE_ARRAY; }
+                    else if (cnt == 0 && p == 0 && lane_u32((uint32_t)inwin, at) && lane_u32((uint32_t)(c64 < left), at)) {
+                        // the stage starts with a record whose bytes it cannot hold: take it alone
+                        if (lane == 0) { v_pos[0] = lane_u32(c, at) + 4; v_len[0] = lane_u32(len, at); }
+                        big = true;
+                        cnt = 1;
+                    }
+                    break;
+                }
             }
+            wave_sync();
+            if (big) {
+                // one record longer than the stage: straight from global memory, all lanes on it
+                const uint32_t blen = v_len[0], bpos = v_pos[0];
+                if (nv + 2 > offsets_cap) { status = PQD_ERR_OFFSETS_TOO_SMALL; arg = (int64_t)(nv + 2); }
+                else if (out + blen > dst_cap) { status = PQD_ERR_DST_TOO_SMALL; arg = (int64_t)(out + blen); }
+                else {
+                    if (lane == 0) offsets[nv] = (uint32_t)out;
+                    for (uint64_t b = lane; b < blen; b += WT) dst[out + b] = src[i + bpos + b];
+                    out += blen;
+                    nv += 1;
+                    p = 0;
+                    i += (uint64_t)bpos + blen;
+                    guess = blen;
+                }
+                restage = true;
+            } else if (cnt == 0) {
+                // nothing staged could be taken: the page is through, or the next record starts a new stage
+                if (p == 0 && status == PQD_OK) status = -1; // a fresh stage that yields nothing: cannot happen, but never spin
+                restage = true;
+            } else {
+                const uint32_t pos = lane < cnt ? v_pos[lane] : 0, len = lane < cnt ? v_len[lane] : 0;
+                const uint32_t incl = wave_inclusive_scan<uint32_t>(len);
+                const uint64_t o = out + (incl - len);
+                // capacity checks in record order (plain.go walks and appends one value at a time)
+                uint32_t cap_err = 0;
+                if (lane < cnt) {
+                    if (nv + lane + 2 > offsets_cap) cap_err = 1;
+                    else if (o + len > dst_cap) cap_err = 2;
+                }
+                const unsigned long long capm = __ballot(cap_err != 0);
+                uint32_t good = cnt;
+                if (capm) {
+                    good = (uint32_t)__builtin_ctzll(capm);
+                    const uint32_t e = lane_u32(cap_err, good);
+                    status = e == 1 ? PQD_ERR_OFFSETS_TOO_SMALL : PQD_ERR_DST_TOO_SMALL;
+                    arg = e == 1 ? (int64_t)(nv + good + 2) : (int64_t)(lane_u64(o, good) + lane_u32(len, good));
+                }
+                const uint32_t mylen = lane < good ? len : 0;
+                if (lane < good) offsets[nv + lane] = (uint32_t)o;
+                // the longest record of the batch sets the number of rounds
+                uint32_t longest = mylen;
+                for (int d = 32; d > 0; d >>= 1) { const uint32_t y = __shfl_xor(longest, d); longest = y > longest ? y : longest; }
+                // four rounds at a time, their LDS reads issued together
+                for (uint32_t r = 0; r * 4 < longest; r += 4) {
+                    uint32_t w[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) w[u] = (r + u) * 4 < mylen ? lds_u32(stage32, pos + (r + u) * 4) : 0u;
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; u++) {
+                        const uint32_t b = (r + u) * 4;
+                        gptr<uint8_t> d = dst + o + b;
+                        if (b + 4 <= mylen) *(gptr<u32_a1>)d = w[u];
+                        else if (b < mylen) for (uint32_t k = 0; b + k < mylen; k++) d[k] = (uint8_t)(w[u] >> (8 * k));
+                    }
+                }
+                if (good > 0) {
+                    out = lane_u64(o, good - 1) + lane_u32(len, good - 1);
+                    nv += good;
+                }
+                if (good < cnt) p = good > 0 ? lane_u32(pos, good - 1) + lane_u32(len, good - 1) : (cnt > 0 ? lane_u32(pos, 0) - 4 : p);
+            }
+            wave_sync();
         }
-        __syncthreads();
-        if (big) {
-            // one record longer than the stage: straight from global memory, all lanes on it
-            const uint32_t blen = v_len[0], bpos = v_pos[0];
-            if (nv + 2 > offsets_cap) { status = PQD_ERR_OFFSETS_TOO_SMALL; arg = (int64_t)(nv + 2); }
-            else if (out + blen > dst_cap) { status = PQD_ERR_DST_TOO_SMALL; arg = (int64_t)(out + blen); }
-            else {
-                if (lane == 0) offsets[nv] = (uint32_t)out;
-                for (uint64_t b = lane; b < blen; b += WT) dst[out + b] = src[i + bpos + b];
-                out += blen;
-                nv += 1;
-                i += (uint64_t)bpos + blen;
-                guess = blen;
-            }
-        } else {
-            const uint32_t pos = lane < cnt ? v_pos[lane] : 0, len = lane < cnt ? v_len[lane] : 0;
-            const uint32_t incl = wave_inclusive_scan<uint32_t>(len);
-            const uint64_t o = out + (incl - len);
-            // capacity checks in record order (plain.go walks and appends one value at a time)
-            uint32_t cap_err = 0;
-            if (lane < cnt) {
-                if (nv + lane + 2 > offsets_cap) cap_err = 1;
-                else if (o + len > dst_cap) cap_err = 2;
-            }
-            const unsigned long long capm = __ballot(cap_err != 0);
-            uint32_t good = cnt;
-            if (capm) {
-                good = (uint32_t)__builtin_ctzll(capm);
-                const uint32_t e = lane_u32(cap_err, good);
-                status = e == 1 ? PQD_ERR_OFFSETS_TOO_SMALL : PQD_ERR_DST_TOO_SMALL;
-                arg = e == 1 ? (int64_t)(nv + good + 2) : (int64_t)(lane_u64(o, good) + lane_u32(len, good));
-            }
-            const uint32_t mylen = lane < good ? len : 0;
-            if (lane < good) offsets[nv + lane] = (uint32_t)o;
-            // the longest record of the batch sets the number of rounds
-            uint32_t longest = mylen;
-            for (int d = 32; d > 0; d >>= 1) { const uint32_t y = __shfl_xor(longest, d); longest = y > longest ? y : longest; }
-            for (uint32_t r = 0; r * 4 < longest; r++) lane_copy(dst + o, stage32, pos, mylen, r);
-            if (good > 0) {
-                out = lane_u64(o, good - 1) + lane_u32(len, good - 1);
-                nv += good;
-                i += (uint64_t)lane_u32(pos, good - 1) + lane_u32(len, good - 1);
-            }
-            if (cnt == 0 && status == PQD_OK) break; // nothing could be taken and nothing failed: cannot happen, but never spin
-        }
-        __syncthreads();
+        if (p > 0) i += p;
+        if (status == -1) { status = PQD_OK; break; }
     }
     if (lane == 0) {
         if (status == PQD_OK) {
@@ -632,7 +659,7 @@ __global__ __launch_bounds__(WT) void dba_kernel(const DevPage* __restrict__ pag
                     stage_fill(stage, data + span0, span1 - span0, lane);
                     staged_base = span0;
                     staged_len = span1 - span0;
-                    __syncthreads();
+                    wave_sync();
                 }
                 const uint32_t* stage32 = reinterpret_cast<const uint32_t*>(stage);
                 const uint32_t so32 = (uint32_t)(s_off - staged_base), p32 = (uint32_t)p_pos, s32 = (uint32_t)s_pos;
@@ -672,7 +699,7 @@ __global__ __launch_bounds__(WT) void dba_kernel(const DevPage* __restrict__ pag
                 reinterpret_cast<uint32_t*>(last)[lane] = cur; // the slow pass and the next fast pass start from here
                 prev_len = last_len;
                 prev_out = lane_u64(o_off, taken + cnt - 1);
-                __syncthreads();
+                wave_sync();
                 taken += cnt;
                 continue;
             }
@@ -690,7 +717,7 @@ __global__ __launch_bounds__(WT) void dba_kernel(const DevPage* __restrict__ pag
                 }
                 // suffix bytes into the LDS copy (as far as it reaches) ...
                 for (uint64_t b = lane; b < s_v && p_v + b < LAST_CAP; b += WT) last[p_v + b] = data[so + b];
-                __syncthreads();
+                wave_sync();
                 // ... the value's first bytes from the LDS copy ...
                 const uint64_t head = len < LAST_CAP ? len : LAST_CAP;
                 for (uint64_t b = lane; b < head; b += WT) dst[oo + b] = last[b];
@@ -701,7 +728,7 @@ __global__ __launch_bounds__(WT) void dba_kernel(const DevPage* __restrict__ pag
                 }
                 prev_len = len;
                 prev_out = oo;
-                __syncthreads();
+                wave_sync();
                 taken += 1;
             }
         }
@@ -714,7 +741,7 @@ __global__ __launch_bounds__(WT) void dba_kernel(const DevPage* __restrict__ pag
             }
             staged_base = next0;
             staged_len = pf_len;
-            __syncthreads();
+            wave_sync();
         }
         if (m > 0) {
             src_base = lane_u64(s_off + s_pos, m - 1);
@@ -1007,7 +1034,7 @@ __global__ __launch_bounds__(WT) void dba_expand_kernel(const DevPage* __restric
                 for (uint32_t e = 0; e < n; e++) img[q + p + t + e] = (uint8_t)(w >> (8 * e));
             }
         }
-        __syncthreads();
+        wave_sync();
 
         // ---- inherited bytes, a dword column at a time ----
         uint32_t longest = p;
@@ -1053,7 +1080,7 @@ __global__ __launch_bounds__(WT) void dba_expand_kernel(const DevPage* __restric
                 for (uint32_t e = 0; e < n; e++) img[q + 4 * c + e] = (uint8_t)(w >> (8 * e));
             }
         }
-        __syncthreads();
+        wave_sync();
 
         // ---- the image goes out: image and destination agree modulo 16 ----
         {
@@ -1066,7 +1093,7 @@ __global__ __launch_bounds__(WT) void dba_expand_kernel(const DevPage* __restric
             for (uint32_t c = lane; c < body; c += WT)
                 *(gptr<u32x4>)(out + head + c * 16) = *reinterpret_cast<const u32x4*>(img + align + head + c * 16);
         }
-        __syncthreads();
+        wave_sync();
     }
 }
 
