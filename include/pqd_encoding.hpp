@@ -181,4 +181,42 @@ private:
     size_t n_;
 };
 
+// The page headers of a column chunk held in memory: the header loop of FilePages.ReadPage
+// (file.go:1193-1259).  `num_values` as in ColumnMetaData, or -1 to walk to the end of the bytes.
+inline std::vector<pqd_page_header> ScanPages(const uint8_t* chunk, size_t n, int64_t num_values = -1) {
+    std::vector<pqd_page_header> out(16);
+    for (;;) {
+        uint64_t found = 0;
+        int64_t arg = 0;
+        int rc = pqd_chunk_scan_pages(chunk, n, num_values, out.data(), out.size(), &found, &arg);
+        if (rc == PQD_ERR_DST_TOO_SMALL) { out.resize(found); continue; }
+        if (rc != PQD_OK) throw Error("PAGE_HEADER", rc, arg);
+        out.resize(found);
+        return out;
+    }
+}
+
+// The parts of the pages of an uncompressed chunk, as Column.decodeDataPageV1 / V2 /
+// decodeDictionary cut them (column.go:733-843, 963-993): items[i] is ready for
+// pqd_batch_create once the caller has set dst (and offsets, dict); parts[i] says which page
+// and which part it is.  `chunk_dev` is where the chunk lies in device memory.
+struct PagePlan {
+    std::vector<pqd_page> items;
+    std::vector<pqd_page_part> parts;
+};
+inline PagePlan PlanPages(const std::vector<pqd_page_header>& headers, const uint8_t* chunk, size_t n, const void* chunk_dev,
+                          const pqd_column_info& column) {
+    PagePlan plan;
+    plan.items.resize(3 * headers.size() + 1);
+    plan.parts.resize(plan.items.size());
+    uint64_t found = 0;
+    int64_t arg = 0;
+    int rc = pqd_chunk_plan_pages(headers.data(), headers.size(), chunk, n, chunk_dev, &column, plan.items.data(), plan.parts.data(),
+                                  plan.items.size(), &found, &arg);
+    if (rc != PQD_OK) throw Error("PAGE", rc, arg);
+    plan.items.resize(found);
+    plan.parts.resize(found);
+    return plan;
+}
+
 } // namespace pqd

@@ -94,6 +94,74 @@ int main() {
         CHECK(!"out-of-range index accepted");
     } catch (const pqd::Error& e) { CHECK(e.cls == pqd::ErrorClass::IndexOutOfBounds && e.arg == 17); }
 
+    // a column chunk put together by hand: a dictionary page and a v1 data page with definition
+    // levels; headers in the thrift compact protocol (0x15 = next field, i32; 0x2c / 0x4c = a struct
+    // two / four fields on; 0x00 = stop)
+    {
+        auto zz = [](std::vector<uint8_t>& o, int32_t v) {
+            uint32_t u = ((uint32_t)v << 1) ^ (uint32_t)(v >> 31);
+            while (u >= 0x80) { o.push_back((uint8_t)(u | 0x80)); u >>= 7; }
+            o.push_back((uint8_t)u);
+        };
+        std::vector<int64_t> dvals{11, 22, 33, 44};
+        std::vector<uint8_t> dict_body((const uint8_t*)dvals.data(), (const uint8_t*)dvals.data() + 32);
+        std::vector<uint8_t> def{1, 1, 0, 1, 0, 1, 1, 1, 1, 0};                      // 7 of 10 slots hold a value
+        std::vector<uint8_t> def_enc(4096);
+        def_enc.resize(pqo_rle_encode_levels(def_enc.data(), def_enc.size(), def.data(), def.size(), 1));
+        std::vector<int32_t> idx{3, 0, 1, 1, 2, 3, 0};
+        std::vector<uint8_t> idx_enc(4096);
+        idx_enc.resize(pqo_rle_dict_encode_int32(idx_enc.data(), idx_enc.size(), idx.data(), idx.size()));
+        std::vector<uint8_t> body;
+        uint32_t dl = (uint32_t)def_enc.size();
+        body.insert(body.end(), (uint8_t*)&dl, (uint8_t*)&dl + 4);
+        body.insert(body.end(), def_enc.begin(), def_enc.end());
+        const size_t values_at = body.size();
+        body.insert(body.end(), idx_enc.begin(), idx_enc.end());
+        std::vector<uint8_t> chunk;
+        // PageHeader{type = DICTIONARY_PAGE, sizes, dictionary_page_header{num_values 4, PLAIN_DICTIONARY}}
+        chunk.push_back(0x15); zz(chunk, 2); chunk.push_back(0x15); zz(chunk, 32); chunk.push_back(0x15); zz(chunk, 32);
+        chunk.push_back(0x4c); chunk.push_back(0x15); zz(chunk, 4); chunk.push_back(0x15); zz(chunk, 2); chunk.push_back(0x00);
+        chunk.push_back(0x00);
+        const size_t dict_at = chunk.size();
+        chunk.insert(chunk.end(), dict_body.begin(), dict_body.end());
+        // PageHeader{type = DATA_PAGE, sizes, data_page_header{num_values 10, PLAIN_DICTIONARY, RLE, RLE}}
+        const size_t second = chunk.size();
+        chunk.push_back(0x15); zz(chunk, 0); chunk.push_back(0x15); zz(chunk, (int32_t)body.size()); chunk.push_back(0x15); zz(chunk, (int32_t)body.size());
+        chunk.push_back(0x2c); chunk.push_back(0x15); zz(chunk, 10); chunk.push_back(0x15); zz(chunk, 2); chunk.push_back(0x15); zz(chunk, 3);
+        chunk.push_back(0x15); zz(chunk, 3); chunk.push_back(0x00);
+        chunk.push_back(0x00);
+        const size_t data_at = chunk.size();
+        chunk.insert(chunk.end(), body.begin(), body.end());
+
+        std::vector<pqd_page_header> hs = pqd::ScanPages(chunk.data(), chunk.size(), 10);
+        CHECK(hs.size() == 2);
+        CHECK(hs[0].type == PQD_PAGE_DICTIONARY && hs[0].num_values == 4 && hs[0].data_offset == dict_at && hs[0].compressed_page_size == 32);
+        CHECK(hs[1].type == PQD_PAGE_DATA && hs[1].num_values == 10 && hs[1].header_offset == second && hs[1].data_offset == data_at);
+        CHECK(hs[1].encoding == PQD_ENC_PLAIN_DICTIONARY && hs[1].definition_level_encoding == PQD_ENC_RLE);
+        pqd_column_info col = {PQD_KIND_INT64, 0, 1, 0};
+        pqd::PagePlan plan = pqd::PlanPages(hs, chunk.data(), chunk.size(), chunk.data(), col);
+        CHECK(plan.items.size() == 3);
+        CHECK(plan.parts[0].role == PQD_PART_DICTIONARY && plan.items[0].encoding == PQD_ENC_PLAIN && plan.items[0].src_len == 32);
+        CHECK(plan.parts[1].role == PQD_PART_DEFINITION_LEVELS && plan.items[1].kind == PQD_KIND_LEVELS && plan.items[1].bit_width == 1);
+        CHECK(plan.parts[1].src_offset == data_at + 4 && plan.items[1].src_len == def_enc.size() && plan.items[1].num_values == 10);
+        CHECK(plan.parts[2].role == PQD_PART_VALUES && plan.items[2].encoding == PQD_ENC_RLE_DICTIONARY && plan.items[2].num_values == -1);
+        CHECK(plan.parts[2].src_offset == data_at + values_at && plan.items[2].src_len == idx_enc.size());
+        // the parts decode to what went in
+        std::vector<uint8_t> dgot;
+        pqd::RLE(1).DecodeLevels(dgot, chunk.data() + plan.parts[1].src_offset, plan.items[1].src_len);
+        dgot.resize(10);
+        CHECK(dgot == def);
+        std::vector<int32_t> igot;
+        pqd::RLEDictionary().DecodeInt32(igot, chunk.data() + plan.parts[2].src_offset, plan.items[2].src_len);
+        igot.resize(7);
+        CHECK(igot == idx);
+        // a chunk cut inside the second header
+        try {
+            pqd::ScanPages(chunk.data(), second + 2, -1);
+            CHECK(!"a truncated page header was accepted");
+        } catch (const pqd::Error& e) { CHECK(e.cls == pqd::ErrorClass::UnexpectedEOF && e.arg == (int64_t)second); }
+    }
+
     std::printf("pqd_encoding.hpp ok\n");
     return 0;
 }
