@@ -95,7 +95,9 @@ int32_t elem_width_of(int32_t kind, int32_t bit_width) {
 constexpr size_t SIDE_BY_SIDE_MAX_ITEMS = 1024;     // batches up to this size fork their families onto side streams
 constexpr int RLE_GRIDS = 4;
 constexpr size_t RLE_CHUNKED_MAX_PAGES = 512;      // batches with more RLE pages than this index them one wavefront each
-constexpr uint64_t RLE_CHUNKED_MIN_BYTES = 16384;   // shorter pages are not worth cutting up
+constexpr uint64_t RLE_CHUNKED_MIN_BYTES = 16384;   // shorter pages are not worth cutting up ...
+constexpr uint64_t RLE_CHUNKED_MIN_BYTES_FEW = 4096; // ... unless the batch holds so few that wavefronts would idle
+constexpr size_t RLE_CHUNKED_FEW_PAGES = 128;
 constexpr int32_t RLE_FAMILY[RLE_GRIDS] = {FAM_RLE, FAM_RLE_BYTES, FAM_RLE_DICT8, FAM_RLE_DICT4};
 inline int rle_grid(int32_t family) {
     for (int g = 0; g < RLE_GRIDS; g++) if (RLE_FAMILY[g] == family) return g;
@@ -353,9 +355,10 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
         uint64_t n_chunks = 0;
         std::vector<uint32_t> per_page;
         if (n_rle <= RLE_CHUNKED_MAX_PAGES) {
+            const uint64_t min_bytes = n_rle <= RLE_CHUNKED_FEW_PAGES ? RLE_CHUNKED_MIN_BYTES_FEW : RLE_CHUNKED_MIN_BYTES;
             for (uint32_t k = 0; k < b->items.size(); k++) {
                 DevPage& d = b->items[k];
-                if (!is_rle(d.family) || d.src_len < RLE_CHUNKED_MIN_BYTES || d.src_len > 0xfff00000ull) continue;
+                if (!is_rle(d.family) || d.src_len < min_bytes || d.src_len > 0xfff00000ull) continue;
                 if (d.num_values >= 0) {
                     // widest the values can be: the declared width, or what the dictionary's size allows
                     uint64_t width = d.bit_width > 0 ? (uint64_t)d.bit_width : 32;
