@@ -53,6 +53,7 @@ struct pqd_batch {
     // generic tile grids for the element-parallel families
     uint64_t max_src[16] = {0}; // longest src of each family, sizes the tile grids
     uint64_t dba_max_values = 0; // most values a DELTA_BYTE_ARRAY page of the batch is expected to hold
+    uint64_t flat_blocks[16] = {0}; // DELTA families decoded tile by tile: most blocks a page may hold (0: not used)
     std::vector<DevResult> h_results;
     ~pqd_batch() {
         if (arena) (void)hipFree(arena);
@@ -287,6 +288,7 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
                 pre.elem_width = 4;
                 pre.lengths_cap = cap;
                 pre.dst_cap = cap * 4;
+                pre.flat_off = 1;
                 const int32_t p_idx = (int32_t)b->items.size();
                 b->items.push_back(pre);
                 DevPage suf = pre;
@@ -437,6 +439,22 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
     const size_t o_ck_state_end = carve(0);
     const size_t o_runs = carve(runs_entries * sizeof(Run));
     const size_t o_lengths = carve(lengths_entries * sizeof(int32_t));
+    // few DELTA pages: block positions and tile sums for the tile-parallel kernels
+    size_t flat_bytes = 0;
+    for (int f : {FAM_DELTA32, FAM_DELTA32_CHAINED, FAM_DELTA64}) {
+        if (b->fam[f].items.empty() || b->fam[f].items.size() > DELTA_FLAT_MAX_PAGES) continue;
+        for (uint32_t k : b->fam[f].items) {
+            DevPage& d = b->items[k];
+            if (d.flat_off) continue;
+            uint64_t values = d.dst_cap / (uint64_t)(d.elem_width > 0 ? d.elem_width : 4) + 1;
+            if (d.num_values >= 0 && (uint64_t)d.num_values < values) values = (uint64_t)d.num_values;
+            if (values > 0x7fffffffull) values = 0x7fffffffull;
+            d.flat_cap = values / 128 + 2;
+            flat_bytes += align_up((d.flat_cap + 2) * sizeof(uint32_t), 16) + (d.flat_cap / 8 + 3) * sizeof(uint64_t);
+            b->flat_blocks[f] = std::max<uint64_t>(b->flat_blocks[f], d.flat_cap);
+        }
+    }
+    const size_t o_flat = carve(flat_bytes);
     b->arena_bytes = std::max<size_t>(off, 256);
     if (hipMalloc(&b->arena, b->arena_bytes) != hipSuccess) { delete b; return PQD_ERR_DEVICE; }
     uint8_t* a = static_cast<uint8_t*>(b->arena);
@@ -462,7 +480,14 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
     b->ck.vals = reinterpret_cast<unsigned long long*>(a + o_ck_vals);
     Run* runs = reinterpret_cast<Run*>(a + o_runs);
     int32_t* lengths = reinterpret_cast<int32_t*>(a + o_lengths);
+    uint8_t* flat = a + o_flat;
     for (DevPage& d : b->items) {
+        if (d.flat_cap > 0) {
+            d.flat_pos = reinterpret_cast<uint32_t*>(flat);
+            flat += align_up((d.flat_cap + 2) * sizeof(uint32_t), 16);
+            d.flat_sum = reinterpret_cast<uint64_t*>(flat);
+            flat += (d.flat_cap / 8 + 3) * sizeof(uint64_t);
+        }
         if (is_rle(d.family)) {
             d.runs = runs; runs += d.runs_cap;
             d.tile_run = reinterpret_cast<uint32_t*>(a + o_rle_tile_run) + d.lengths_cap;
@@ -527,9 +552,10 @@ int pqd_batch_launch(pqd_batch* b, void* hip_stream) {
         s_rle = b->ctx->side[0]; s_flat = b->ctx->side[1]; s_walk = b->ctx->side[2];
         for (hipStream_t st : b->ctx->side) PQD_HIP(hipStreamWaitEvent(st, b->fork, 0));
     }
-    launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA32].dev, (uint32_t)b->fam[FAM_DELTA32].items.size(), false, s);
-    launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA32_CHAINED].dev, (uint32_t)b->fam[FAM_DELTA32_CHAINED].items.size(), false, s);
-    launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA64].dev, (uint32_t)b->fam[FAM_DELTA64].items.size(), true, s);
+    launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA32].dev, (uint32_t)b->fam[FAM_DELTA32].items.size(), false, b->flat_blocks[FAM_DELTA32], s);
+    launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA32_CHAINED].dev, (uint32_t)b->fam[FAM_DELTA32_CHAINED].items.size(), false,
+                 b->flat_blocks[FAM_DELTA32_CHAINED], s);
+    launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA64].dev, (uint32_t)b->fam[FAM_DELTA64].items.size(), true, b->flat_blocks[FAM_DELTA64], s);
     launch_rle_chunked(b->d_items, b->d_results, b->ck, s_rle);
     for (int g = 0; g < RLE_GRIDS; g++) {
         const FamilyList& f = b->fam[RLE_FAMILY[g]];

@@ -14,6 +14,8 @@
 // registers from tile to tile, so a page needs no cross-workgroup hand-off and
 // is read exactly once.  Parallelism comes from the batch: one workgroup per
 // page, eight workgroups per CU.
+#include <algorithm>
+
 #include "pqd_internal.h"
 
 namespace pqd {
@@ -334,6 +336,7 @@ __device__ inline void decode_tile(const uint32_t* ring, uint64_t* wtot, const S
 // ---------------------------------------------------------------------------
 
 constexpr uint64_t FAST_DONE = 0x46415354444f4e45ull; // marks a result the fast kernel produced
+constexpr uint64_t FLAT_PENDING = 0x464c415450454e44ull; // marks a page the tile-parallel kernels (delta_flat_*) decode
 constexpr uint32_t TBL_TILES = 4;    // tiles one walk can describe
 constexpr uint32_t TBL_SLOTS = TBL_TILES * 32;  // miniblocks one walk can describe
 constexpr uint32_t TBL_BLOCKS = TBL_TILES * 8; // blocks one walk can describe
@@ -449,6 +452,7 @@ void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict_
     const uint32_t mis = (uint32_t)(reinterpret_cast<uintptr_t>(src) & 15);
     gptr<const uint8_t> base = as_global(src - mis);
     gptr<U> out = (gptr<U>)(pg.dst);
+    if (res->aux == FLAT_PENDING) return; // uniform: decoded tile by tile (delta_flat_*)
     if (src_len > FAST_MAX_BYTES) { // uniform: left to the general kernel, which addresses with 64 bits
         if (tid == 0) res->aux = 0;
         return;
@@ -793,7 +797,7 @@ __global__ __launch_bounds__(DT) void delta_decode_kernel(const DevPage* __restr
     gptr<const uint8_t> base = as_global(src - mis);       // ring-space 0
     const uint64_t end = mis + src_len;    // ring-space end of page
     gptr<U> out = (gptr<U>)(pg.dst);
-    if (res->aux == FAST_DONE) return; // uniform: the fast kernel decoded this page
+    if (res->aux == FAST_DONE || res->aux == FLAT_PENDING) return; // uniform: the fast or the tile-parallel kernels decoded this page
 
     uint64_t c_next = 0;
     ring_fill(sh.ring, base, end, mis, c_next);
@@ -937,11 +941,309 @@ __global__ __launch_bounds__(DT) void delta_decode_kernel(const DevPage* __restr
     }
 }
 
+// ---------------------------------------------------------------------------
+// Tile-parallel path for batches of few pages.  One workgroup per page leaves most of the
+// chip idle when a batch holds a few hundred pages, and its tile loop is a chain of LDS round
+// trips and barriers (about 1.3 us per 1024 values whatever the width).  Pages with the
+// writers' usual geometry (blocks of 128 values, four miniblocks) are decoded here instead:
+//   delta_flat_walk   per page, finds where every block starts out of a 16 KB window of the
+//                     stream in LDS: lane l guesses that block l starts l * S bytes after the
+//                     first (S: the size most blocks have had), reads the sixteen bytes there,
+//                     and the guess holds for the lanes whose predecessors all measured S; 64
+//                     blocks per round when the widths are steady.  Anything unusual -- a
+//                     header problem, a width over the value width, data cut short, sizes that
+//                     keep changing -- leaves the page to the kernels above, untouched.
+//   delta_flat_tile   a workgroup per tile of 1024 deltas (8 blocks), twice: first only the
+//                     sum of the tile's deltas, then the values themselves, each tile starting
+//                     from the first value plus the sums of the tiles before it.  A tile
+//                     loads its bytes, unpacks, scans, stores and is done: the form in which
+//                     reads do not queue behind the page's own stores.
+// ---------------------------------------------------------------------------
+
+constexpr uint32_t FLAT_STAGE = 8 * (10 + 4 + 4 * 256) + 64; // most bytes eight blocks take, and slack
+
+__device__ inline uint32_t lane_u32_or_u64(uint32_t v) { return lane_u32(v, 63); }
+__device__ inline uint64_t lane_u32_or_u64(uint64_t v) { return lane_u64(v, 63); }
+
+constexpr uint32_t FLAT_WIN = 16384; // bytes of the stream the walk keeps in LDS at a time
+
+struct FlatWalkState {
+    uint32_t pos, found, guess, alt, rounds;
+    int32_t ok, done;
+};
+
+template <typename U>
+__global__ __launch_bounds__(DT) void delta_flat_walk(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                      const uint32_t* __restrict__ items) {
+    __shared__ __attribute__((aligned(16))) uint32_t win[FLAT_WIN / 4 + 8];
+    __shared__ uint8_t head[64];
+    __shared__ FlatWalkState st;
+    const uint32_t item = items[blockIdx.x];
+    const DevPage& pg = pages[item];
+    DevResult* res = &results[item];
+    const uint32_t tid = threadIdx.x, lane = tid & 63;
+    uint64_t src_skip = 0;
+    if (pg.chain >= 0) src_skip = results[pg.chain].consumed;
+    gptr<const uint8_t> src = as_global(pg.src) + src_skip;
+    const uint64_t src_len = pg.src_len > src_skip ? pg.src_len - src_skip : 0;
+    gptr<uint32_t> pos_out = as_global(pg.flat_pos);
+    bool ok = pg.flat_pos != nullptr && src_len >= 4 && src_len <= FAST_MAX_BYTES;
+    // ---- page header (binary_packed.go:409-452): anything but the plain case is not for this path ----
+    if (tid < 64) head[tid] = ok && tid < src_len ? src[tid] : (uint8_t)0;
+    __syncthreads();
+    uint64_t hv[4] = {0, 0, 0, 0};
+    uint32_t p = 0;
+    for (int f = 0; f < 4 && ok; f++) {
+        uint64_t x = 0;
+        uint32_t sft = 0, i = 0;
+        for (;; i++) {
+            if (p + i >= 40 || p + i >= src_len || i >= 9) { ok = false; break; }
+            const uint32_t b = head[p + i];
+            x |= (uint64_t)(b & 0x7f) << sft;
+            sft += 7;
+            if (b < 0x80) break;
+        }
+        hv[f] = x;
+        p += i + 1;
+    }
+    const uint64_t total = hv[2];
+    const int64_t first = unzigzag(hv[3]);
+    ok = ok && hv[0] == 128 && hv[1] == 4 && total >= 2 && total <= 0x7fffffffull && total * sizeof(U) <= pg.dst_cap;
+    if (sizeof(U) == 4) ok = ok && first >= -2147483647LL - 1 && first <= 2147483647LL;
+    const uint32_t n_deltas = ok ? (uint32_t)total - 1 : 0;
+    const uint32_t n_blocks = (n_deltas + 127) / 128;
+    ok = ok && (uint64_t)n_blocks + 1 <= pg.flat_cap;
+    if (!ok) { // uniform
+        if (tid == 0) res->aux = 0;
+        return;
+    }
+    // ---- block starts.  Positions below are in "window space": stream offset + mis, so that
+    // window space 0 is the 16-byte boundary at or before the stream's first byte. ----
+    const uint32_t mis = (uint32_t)((uintptr_t)(pg.src + src_skip) & 15);
+    gptr<const uint8_t> base = src - mis;
+    const uint32_t end = mis + (uint32_t)src_len;
+    if (tid == 0) { st.pos = mis + p; st.found = 0; st.guess = 0; st.alt = 0; st.rounds = 0; st.ok = 1; st.done = 0; }
+    __syncthreads();
+    for (;;) {
+        // the window: FLAT_WIN bytes from the 16-byte boundary at or before the next block
+        const uint32_t w0 = st.pos & ~15u;
+        for (uint32_t c = tid * 16; c < FLAT_WIN; c += DT * 16) {
+            u32x4 w = (u32x4)(0u);
+            if (w0 + c < end) w = *(gptr<const u32x4>)(base + w0 + c);
+            *reinterpret_cast<u32x4*>(&win[c / 4]) = w;
+        }
+        __syncthreads();
+        if (tid < 64) {
+            uint32_t pos = st.pos, found = st.found, guess = st.guess, alt = st.alt, rounds = st.rounds;
+            bool good_walk = true, done = false;
+            const bool to_end = w0 + FLAT_WIN >= end; // the window reaches the end of the stream
+            while (found < n_blocks) {
+                const uint32_t bidx = found + lane;
+                const uint64_t cand64 = (uint64_t)pos + (uint64_t)lane * guess;
+                const bool resident = cand64 + 16 <= (uint64_t)w0 + FLAT_WIN || (to_end && cand64 + 5 <= end);
+                if (!lane_u32((uint32_t)resident, 0)) break; // the next block lies past the window: move it
+                const uint32_t cand = (uint32_t)cand64;
+                uint32_t size = 0;
+                bool good = false;
+                if (bidx < n_blocks && resident && cand64 + 5 <= end) {
+                    const uint32_t at = cand - w0, d = at >> 2, sh8 = (at & 3) * 8;
+                    const uint32_t x0 = win[d], x1 = win[d + 1], x2 = win[d + 2], x3 = win[d + 3], x4 = win[d + 4];
+                    const uint64_t lo = ((uint64_t)__builtin_amdgcn_alignbit(x2, x1, sh8) << 32) | __builtin_amdgcn_alignbit(x1, x0, sh8);
+                    const uint64_t hi = ((uint64_t)__builtin_amdgcn_alignbit(x4, x3, sh8) << 32) | __builtin_amdgcn_alignbit(x3, x2, sh8);
+                    uint32_t k, wd;
+                    if (quick_header(lo, hi, k, wd)) {
+                        const uint32_t bvals = n_deltas - bidx * 128 < 128 ? n_deltas - bidx * 128 : 128;
+                        const uint32_t need = (bvals + 31) / 32;
+                        uint32_t bits = 0, top = 0;
+                        for (uint32_t m = 0; m < need; m++) {
+                            const uint32_t bw = (wd >> (8 * m)) & 0xff;
+                            bits += bw;
+                            top = bw > top ? bw : top;
+                        }
+                        size = k + 4 + 4 * bits;
+                        // a miniblock cut short is zero padded by the reference: not on this path
+                        good = top <= Elem<U>::max_bw && (uint64_t)cand + size <= end;
+                    }
+                }
+                const unsigned long long goodmask = __ballot(good);
+                const unsigned long long same = __ballot(good && size == guess);
+                const uint32_t lead = same == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~same);
+                uint32_t valid = lead < 64 ? lead + (uint32_t)((goodmask >> lead) & 1) : 64u;
+                if (valid > n_blocks - found) valid = n_blocks - found;
+                if (valid == 0) { good_walk = false; break; }
+                if (lane < valid) pos_out[bidx] = cand - mis;
+                const uint32_t last = valid - 1;
+                const uint32_t l_size = lane_u32(size, last);
+                pos = lane_u32(cand, last) + l_size;
+                found += valid;
+                // the size most blocks have stays the guess: an odd one is adopted only when it comes twice in a row
+                if (l_size != guess) {
+                    if (guess == 0 || l_size == alt) guess = l_size;
+                    alt = l_size;
+                }
+                rounds++;
+                // Block sizes that keep changing make this walk slower than decoding the page the
+                // usual way (a round is a dependent chain of LDS reads and cross-lane moves, about
+                // half a microsecond): give up early, before much is spent.
+                if (rounds >= 4 && found < rounds * 16 && found < n_blocks) { good_walk = false; break; }
+            }
+            if (found == n_blocks && good_walk) done = true;
+            if (tid == 0) {
+                st.pos = pos; st.found = found; st.guess = guess; st.alt = alt; st.rounds = rounds;
+                st.ok = good_walk ? 1 : 0;
+                st.done = done ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        if (!st.ok || st.done) break;
+    }
+    if (tid == 0) {
+        if (st.ok && st.done) {
+            pos_out[n_blocks] = st.pos - mis;
+            as_global(pg.flat_sum)[(n_deltas + TILE - 1) / TILE] = (uint64_t)first; // behind the tile sums
+            res->status = PQD_OK;
+            res->arg = 0;
+            res->out_values = total;
+            res->out_bytes = total * sizeof(U);
+            res->bw = 0;
+            res->total = total;
+            res->n_runs = n_blocks;
+            res->consumed = src_skip + (st.pos - mis);
+            res->aux = FLAT_PENDING;
+        } else {
+            res->aux = 0;
+        }
+    }
+}
+
+// grid.x = pages, grid.y = tile slots.  STORE false: flat_sum[tile] = sum of the tile's deltas;
+// STORE true: the tile starts from the first value plus the sums of the tiles before it, and the
+// values are written.
+template <typename U, bool STORE>
+__global__ __launch_bounds__(DT) void delta_flat_tile(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                      const uint32_t* __restrict__ items) {
+    __shared__ __attribute__((aligned(16))) uint32_t stage[FLAT_STAGE / 4 + 8];
+    __shared__ uint64_t wtot[DT / 64];
+    const uint32_t item = items[blockIdx.x];
+    const DevResult& rr = results[item];
+    if (rr.aux != FLAT_PENDING) return;
+    const DevPage& pg = pages[item];
+    uint64_t src_skip = 0;
+    if (pg.chain >= 0) src_skip = results[pg.chain].consumed;
+    gptr<const uint8_t> src = as_global(pg.src) + src_skip;
+    gptr<const uint32_t> bpos = (gptr<const uint32_t>)as_global(pg.flat_pos);
+    gptr<uint64_t> sums = as_global(pg.flat_sum);
+    gptr<U> out = (gptr<U>)(pg.dst);
+    const uint32_t n_deltas = (uint32_t)rr.total - 1, n_blocks = (uint32_t)rr.n_runs;
+    const uint32_t n_tiles = (n_deltas + TILE - 1) / TILE;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t tile = blockIdx.y; tile < n_tiles; tile += gridDim.y) {
+        const uint32_t b0 = tile * 8;
+        const uint32_t nb = n_blocks - b0 < 8 ? n_blocks - b0 : 8;
+        const uint32_t p0 = bpos[b0], p1 = bpos[b0 + nb];
+        // the tile's bytes, from the 16-byte boundary at or before p0; what is read past p1 is never used
+        const uint64_t a0 = ((uintptr_t)(pg.src + src_skip) + p0) & 15;
+        gptr<const uint8_t> from = src + p0 - a0;
+        const uint32_t bytes = (uint32_t)a0 + (p1 - p0);
+        for (uint32_t c = tid * 16; c < bytes; c += DT * 16)
+            *reinterpret_cast<u32x4*>(&stage[c / 4]) = *(gptr<const u32x4>)(from + c);
+        __syncthreads();
+        const uint32_t count = n_deltas - tile * TILE < TILE ? n_deltas - tile * TILE : TILE;
+        const uint32_t j = tid * 4;
+        U v[4] = {0, 0, 0, 0};
+        if (j < count) {
+            const uint32_t blk = tid >> 5, mb = (tid >> 3) & 3, within = (tid & 7) * 4;
+            const uint32_t at = (uint32_t)a0 + (bpos[b0 + blk] - p0);     // block header in the stage
+            const uint32_t d = at >> 2, sh8 = (at & 3) * 8;
+            const uint32_t w0 = stage[d], w1 = stage[d + 1], w2 = stage[d + 2], w3 = stage[d + 3], w4 = stage[d + 4];
+            const uint64_t lo = ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, sh8) << 32) | __builtin_amdgcn_alignbit(w1, w0, sh8);
+            const uint64_t hi = ((uint64_t)__builtin_amdgcn_alignbit(w4, w3, sh8) << 32) | __builtin_amdgcn_alignbit(w3, w2, sh8);
+            uint32_t k, wd;
+            quick_header(lo, hi, k, wd);
+            const U md = (U)unzigzag(quick_uvarint(lo, hi, k));
+            uint32_t off = at + k + 4;
+            for (uint32_t m = 0; m < mb; m++) off += 4 * ((wd >> (8 * m)) & 0xff);
+            const uint32_t bw = (wd >> (8 * mb)) & 0xff;
+            const uint32_t bit0 = within * bw;
+            const uint32_t byte0 = off + (bit0 >> 3);
+            const uint32_t dw = byte0 >> 2;
+            const uint32_t sft = (byte0 & 3) * 8 + (bit0 & 7);
+            const uint32_t mask_lo = bw >= 32 ? 0xffffffffu : ((1u << bw) - 1);
+            const uint32_t mask_hi = bw <= 32 ? 0u : (bw >= 64 ? 0xffffffffu : ((1u << (bw - 32)) - 1));
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t b = sft + i * bw;
+                const uint32_t* q = stage + dw + (b >> 5);
+                const uint32_t x0 = q[0], x1 = q[1];
+                const uint32_t f_lo = __builtin_amdgcn_alignbit(x1, x0, b) & mask_lo;
+                U dlt;
+                if (sizeof(U) == 8) {
+                    const uint32_t x2 = q[2];
+                    const uint32_t f_hi = __builtin_amdgcn_alignbit(x2, x1, b) & mask_hi;
+                    dlt = (U)(((uint64_t)f_hi << 32) | f_lo);
+                } else {
+                    dlt = (U)f_lo;
+                }
+                dlt += md;
+                v[i] = (j + i < count) ? dlt : (U)0;
+            }
+        }
+        v[1] += v[0]; v[2] += v[1]; v[3] += v[2];
+        const U x = wave_inclusive_scan<U>(v[3]);
+        if (lane == 63) wtot[wave] = (uint64_t)x;
+        __syncthreads();
+        U wave_prefix = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < DT / 64; w++) {
+            const U t = (U)wtot[w];
+            if (w < (int)wave) wave_prefix += t;
+            all += t;
+        }
+        if (!STORE) {
+            if (tid == 0) sums[tile] = (uint64_t)all;
+        } else {
+            // the value the tile starts from: the first value plus the sums of the tiles before it
+            U part = 0;
+            for (uint32_t t = tid; t < tile; t += DT) part += (U)sums[t];
+            part = lane_u32_or_u64(wave_inclusive_scan<U>(part));
+            __syncthreads(); // everybody has read the wave totals of the tile's own scan
+            if (lane == 63) wtot[wave] = (uint64_t)part;
+            __syncthreads();
+            U carry = (U)sums[n_tiles]; // the first value, left there by the walk
+            for (int w = 0; w < DT / 64; w++) carry += (U)wtot[w];
+            const U e = carry + wave_prefix + (x - v[3]);
+            U r[4] = {(U)(e + v[0]), (U)(e + v[1]), (U)(e + v[2]), (U)(e + v[3])};
+            const uint32_t done = tile * TILE;
+            if (count == TILE) {
+                tile_store_shifted_full<U>(out, done, e, r);
+                if (tile + 1 == n_tiles && tid == DT - 1) out[done + TILE] = r[3];
+            } else {
+                tile_store_shifted_partial<U>(out, done, count, e, r);
+            }
+        }
+        __syncthreads(); // the stage and the wave totals are free again
+    }
+}
+
 } // namespace
 
 void launch_delta(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, bool is64,
-                  hipStream_t stream) {
+                  uint64_t flat_max_blocks, hipStream_t stream) {
     if (n_items == 0) return;
+    if (flat_max_blocks > 0) {
+        // few pages: the tile-parallel kernels take the pages they can, the kernels below the rest
+        uint64_t tiles = (flat_max_blocks + 7) / 8;
+        const uint32_t slots = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(tiles, 1), std::max<uint64_t>(1, 16384 / n_items));
+        if (is64) {
+            hipLaunchKernelGGL(delta_flat_walk<uint64_t>, dim3(n_items), dim3(DT), 0, stream, pages, results, items);
+            hipLaunchKernelGGL((delta_flat_tile<uint64_t, false>), dim3(n_items, slots), dim3(DT), 0, stream, pages, results, items);
+            hipLaunchKernelGGL((delta_flat_tile<uint64_t, true>), dim3(n_items, slots), dim3(DT), 0, stream, pages, results, items);
+        } else {
+            hipLaunchKernelGGL(delta_flat_walk<uint32_t>, dim3(n_items), dim3(DT), 0, stream, pages, results, items);
+            hipLaunchKernelGGL((delta_flat_tile<uint32_t, false>), dim3(n_items, slots), dim3(DT), 0, stream, pages, results, items);
+            hipLaunchKernelGGL((delta_flat_tile<uint32_t, true>), dim3(n_items, slots), dim3(DT), 0, stream, pages, results, items);
+        }
+    }
     if (is64) {
         hipLaunchKernelGGL(delta_fast_kernel<uint64_t>, dim3(n_items), dim3(DT), 0, stream, pages, results, items);
         hipLaunchKernelGGL(delta_decode_kernel<uint64_t>, dim3(n_items), dim3(DT), 0, stream, pages, results, items);

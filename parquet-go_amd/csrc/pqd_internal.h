@@ -60,6 +60,13 @@ struct DevPage {
     int32_t chain;        // index of the item whose `consumed` gives this item's src offset, or -1
     int32_t fused;        // RLE family: indices go straight through the dictionary gather
     int32_t ck_index;     // RLE family: position in the list of pages indexed chunk by chunk, or -1
+    // DELTA families, batches of few pages: where each block of 128 values starts (flat_cap + 1
+    // entries) and one sum per tile of 1024 values, for the tile-parallel kernels; null otherwise
+    uint32_t* flat_pos;
+    uint64_t* flat_sum;
+    uint64_t flat_cap;    // blocks
+    int32_t flat_off;     // nonzero: never on the tile-parallel path (length streams of DELTA_BYTE_ARRAY: widths change all the time)
+    int32_t reserved;
 };
 
 struct DevResult {
@@ -150,7 +157,8 @@ __device__ inline void set_status(DevResult* r, int32_t status, int64_t arg) {
 
 // Kernel launchers (defined in the .hip files).
 void launch_delta(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, bool is64,
-                  hipStream_t stream);
+                  uint64_t flat_max_blocks, hipStream_t stream);
+constexpr size_t DELTA_FLAT_MAX_PAGES = 256; // families with more pages than this fill the chip with one workgroup per page
 void launch_rle_index(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, const uint32_t* pk_flag,
                       hipStream_t stream);
 

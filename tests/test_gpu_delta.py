@@ -196,3 +196,80 @@ def test_dst_too_small_reports_needed_size():
     assert out.status == P.STATUS.DST_TOO_SMALL and out.arg == 8000
     out = decode([spec(P.ENC.DELTA_BINARY_PACKED, P.KIND.INT64, O.delta_encode_int64(v), dst_cap=8000)], grow=False)[0]
     assert out.status == 0 and np.array_equal(out.data.view(np.int64), v)
+
+
+def _few(cases, kind, dtype, oracle_fn, **kw):
+    # batches of at most 200 pages: the regime in which pages with blocks of 128 / 4 miniblocks and
+    # steady block sizes are decoded tile by tile by many workgroups instead of one per page
+    for k in range(0, len(cases), 200):
+        _run(cases[k: k + 200], kind, dtype, oracle_fn, **kw)
+
+
+def test_few_pages_steady_widths():
+    P = pkg()
+    rng = np.random.default_rng(41)
+    c64, c32 = [], []
+    sizes = (2, 3, 32, 33, 128, 129, 130, 160, 161, 1023, 1024, 1025, 1026, 1153, 2048, 2049, 4097, 131072, 131073, 300001)
+    for k, n in enumerate(sizes):
+        for bw in (0, 1, 7, 12, 31, 32, 33, 48, 63):
+            # every miniblock holds its own extremes, so that all widths (and block sizes) are the same
+            base = rng.integers(0, 1 << bw, size=n, dtype=np.uint64) if bw else np.zeros(n, np.uint64)
+            if bw:
+                base[0::32] = 0
+                base[1::32] = (1 << bw) - 1
+            d = base.astype(np.int64) + 5
+            v = np.cumsum(d.astype(np.uint64), dtype=np.uint64).view(np.int64) + np.int64(-(1 << 40))
+            if n > 4097 and bw not in (0, 12, 33):
+                continue
+            c64.append((f"i64-n{n}-bw{bw}", O.delta_encode_int64(v), (k + bw) % 16))
+            if bw <= 31:
+                v32 = (np.cumsum(d.astype(np.uint64), dtype=np.uint64) & 0xffffffff).astype(np.uint32).view(np.int32)
+                c32.append((f"i32-n{n}-bw{bw}", O.delta_encode_int32(v32), (k + bw + 3) % 16))
+    _few(c64, P.KIND.INT64, np.int64, O.delta_decode_int64)
+    _few(c32, P.KIND.INT32, np.int32, O.delta_decode_int32)
+
+
+def test_few_pages_odd_blocks_and_declined_pages():
+    P = pkg()
+    rng = np.random.default_rng(42)
+    cases = []
+    n = 50000
+    # steady widths with an odd block now and then (a min delta whose varint is a byte longer, a narrower miniblock)
+    d = rng.integers(100, 100 + 4096, size=n, dtype=np.int64)
+    d[0::32] = 100
+    d[1::32] = 100 + 4095
+    for at in (128 * 7, 128 * 8, 128 * 50, 128 * 51, 128 * 200, 128 * 389):
+        d[at: at + 128] += 1 << 20          # longer min delta
+    d[128 * 100 + 32: 128 * 100 + 64] = 100  # a miniblock of width 0
+    cases.append(("odd-blocks", O.delta_encode_int64(np.cumsum(d)), 5))
+    # widths that change all the time: declined by the walk, decoded by the page-per-workgroup kernel
+    w = rng.integers(0, 40, size=n // 32 + 1)
+    d2 = np.concatenate([rng.integers(0, 1 << int(b), size=32, dtype=np.uint64) if b else np.zeros(32, np.uint64) for b in w])[:n]
+    cases.append(("changing-widths", O.delta_encode_int64(np.cumsum(d2, dtype=np.uint64).view(np.int64)), 9))
+    # geometry the tile-parallel path does not take
+    cases.append(("blocks-of-256", O.delta_encode_int64(np.cumsum(d), 256, 8), 1))
+    # a stream cut short: inside a header, inside a miniblock (zero padded), before the last block
+    enc = O.delta_encode_int64(np.cumsum(d))
+    for cut in (len(enc) - 1, len(enc) - 100, len(enc) // 2, 40, 7):
+        cases.append((f"cut-{cut}", enc[:cut], cut % 16))
+    # the total says more values than there are blocks for
+    cases.append(("tail-garbage", enc + bytes(50), 3))
+    _few(cases, P.KIND.INT64, np.int64, O.delta_decode_int64)
+    # a destination that is too small is reported, not written
+    out = decode([spec(P.ENC.DELTA_BINARY_PACKED, P.KIND.INT64, enc, dst_cap=8 * 1000)], grow=False)[0]
+    assert out.status == P.STATUS.DST_TOO_SMALL and out.arg == 8 * n
+
+
+def test_few_pages_length_streams_chain():
+    # DELTA_LENGTH_BYTE_ARRAY with equal lengths: the length stream takes the tile-parallel path and
+    # the bytes start where it ended
+    P = pkg()
+    rng = np.random.default_rng(43)
+    for n in (1, 2, 129, 5000, 40000):
+        vals = [bytes(rng.integers(0, 256, size=24, dtype=np.uint8)) for _ in range(n)]
+        enc = O.dlba_encode(vals)
+        out = decode([spec(P.ENC.DELTA_LENGTH_BYTE_ARRAY, P.KIND.BYTE_ARRAY, enc, misalign=n % 16)])[0]
+        want = O.dlba_decode(enc)
+        assert out.status == 0 and out.out_values == n and out.consumed == want.consumed
+        assert out.data.tobytes() == b"".join(vals)
+        assert np.array_equal(out.offsets[: n + 1], want.offsets)
