@@ -1124,6 +1124,7 @@ __global__ __launch_bounds__(DT) void delta_flat_tile(const DevPage* __restrict_
                                                       const uint32_t* __restrict__ items) {
     __shared__ __attribute__((aligned(16))) uint32_t stage[FLAT_STAGE / 4 + 8];
     __shared__ uint64_t wtot[DT / 64];
+    __shared__ uint32_t bp[9];
     const uint32_t item = items[blockIdx.x];
     const DevResult& rr = results[item];
     if (rr.aux != FLAT_PENDING) return;
@@ -1140,7 +1141,13 @@ __global__ __launch_bounds__(DT) void delta_flat_tile(const DevPage* __restrict_
     for (uint32_t tile = blockIdx.y; tile < n_tiles; tile += gridDim.y) {
         const uint32_t b0 = tile * 8;
         const uint32_t nb = n_blocks - b0 < 8 ? n_blocks - b0 : 8;
-        const uint32_t p0 = bpos[b0], p1 = bpos[b0 + nb];
+        // one trip to memory for everything that is known before the bytes: the block starts of the
+        // tile and (second pass) the sums of the tiles before it
+        if (tid <= 8) bp[tid] = bpos[b0 + (tid < nb ? tid : nb)];
+        U part = 0;
+        if (STORE) for (uint32_t t = tid; t < tile; t += DT) part += (U)sums[t];
+        __syncthreads();
+        const uint32_t p0 = bp[0], p1 = bp[nb];
         // the tile's bytes, from the 16-byte boundary at or before p0; what is read past p1 is never used
         const uint64_t a0 = ((uintptr_t)(pg.src + src_skip) + p0) & 15;
         gptr<const uint8_t> from = src + p0 - a0;
@@ -1153,7 +1160,7 @@ __global__ __launch_bounds__(DT) void delta_flat_tile(const DevPage* __restrict_
         U v[4] = {0, 0, 0, 0};
         if (j < count) {
             const uint32_t blk = tid >> 5, mb = (tid >> 3) & 3, within = (tid & 7) * 4;
-            const uint32_t at = (uint32_t)a0 + (bpos[b0 + blk] - p0);     // block header in the stage
+            const uint32_t at = (uint32_t)a0 + (bp[blk] - p0);     // block header in the stage
             const uint32_t d = at >> 2, sh8 = (at & 3) * 8;
             const uint32_t w0 = stage[d], w1 = stage[d + 1], w2 = stage[d + 2], w3 = stage[d + 3], w4 = stage[d + 4];
             const uint64_t lo = ((uint64_t)__builtin_amdgcn_alignbit(w2, w1, sh8) << 32) | __builtin_amdgcn_alignbit(w1, w0, sh8);
@@ -1203,8 +1210,6 @@ __global__ __launch_bounds__(DT) void delta_flat_tile(const DevPage* __restrict_
             if (tid == 0) sums[tile] = (uint64_t)all;
         } else {
             // the value the tile starts from: the first value plus the sums of the tiles before it
-            U part = 0;
-            for (uint32_t t = tid; t < tile; t += DT) part += (U)sums[t];
             part = lane_u32_or_u64(wave_inclusive_scan<U>(part));
             __syncthreads(); // everybody has read the wave totals of the tile's own scan
             if (lane == 63) wtot[wave] = (uint64_t)part;
