@@ -965,7 +965,9 @@ constexpr uint32_t FLAT_STAGE = 8 * (10 + 4 + 4 * 256) + 64; // most bytes eight
 __device__ inline uint32_t lane_u32_or_u64(uint32_t v) { return lane_u32(v, 63); }
 __device__ inline uint64_t lane_u32_or_u64(uint64_t v) { return lane_u64(v, 63); }
 
-constexpr uint32_t FLAT_WIN = 16384; // bytes of the stream the walk keeps in LDS at a time
+constexpr uint32_t FLAT_STRIDE = 16384;            // the walk's windows start this far apart ...
+constexpr uint32_t FLAT_WIN = FLAT_STRIDE + 64;    // ... and overlap by 64 bytes, so that a block header lies wholly in one of them
+constexpr uint32_t FLAT_WIN_LOADS = (FLAT_WIN + DT * 16 - 1) / (DT * 16);
 
 struct FlatWalkState {
     uint32_t pos, found, guess, alt, rounds;
@@ -975,7 +977,7 @@ struct FlatWalkState {
 template <typename U>
 __global__ __launch_bounds__(DT) void delta_flat_walk(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
                                                       const uint32_t* __restrict__ items) {
-    __shared__ __attribute__((aligned(16))) uint32_t win[FLAT_WIN / 4 + 8];
+    __shared__ __attribute__((aligned(16))) uint32_t wins[2][FLAT_WIN_LOADS * DT * 4 + 8];
     __shared__ uint8_t head[64];
     __shared__ FlatWalkState st;
     const uint32_t item = items[blockIdx.x];
@@ -1024,15 +1026,32 @@ __global__ __launch_bounds__(DT) void delta_flat_walk(const DevPage* __restrict_
     const uint32_t end = mis + (uint32_t)src_len;
     if (tid == 0) { st.pos = mis + p; st.found = 0; st.guess = 0; st.alt = 0; st.rounds = 0; st.ok = 1; st.done = 0; }
     __syncthreads();
-    for (;;) {
-        // the window: FLAT_WIN bytes from the 16-byte boundary at or before the next block
-        const uint32_t w0 = st.pos & ~15u;
-        for (uint32_t c = tid * 16; c < FLAT_WIN; c += DT * 16) {
-            u32x4 w = (u32x4)(0u);
-            if (w0 + c < end) w = *(gptr<const u32x4>)(base + w0 + c);
-            *reinterpret_cast<u32x4*>(&win[c / 4]) = w;
+    // Window i holds window-space bytes [i * FLAT_STRIDE, i * FLAT_STRIDE + FLAT_WIN); the walk goes
+    // through the windows in order, and window i + 1 is on its way from memory while window i is walked.
+    auto load_window = [&](uint32_t wi, u32x4 (&regs)[FLAT_WIN_LOADS]) {
+#pragma unroll
+        for (uint32_t u = 0; u < FLAT_WIN_LOADS; u++) {
+            const uint64_t at = (uint64_t)wi * FLAT_STRIDE + (uint64_t)(u * DT + tid) * 16;
+            regs[u] = (u32x4)(0u);
+            if (at < end) regs[u] = *(gptr<const u32x4>)(base + at);
         }
-        __syncthreads();
+    };
+    auto put_window = [&](uint32_t wi, const u32x4 (&regs)[FLAT_WIN_LOADS]) {
+#pragma unroll
+        for (uint32_t u = 0; u < FLAT_WIN_LOADS; u++) *reinterpret_cast<u32x4*>(&wins[wi & 1][(u * DT + tid) * 4]) = regs[u];
+    };
+    uint32_t wi = (mis + p) / FLAT_STRIDE;
+    {
+        u32x4 regs[FLAT_WIN_LOADS];
+        load_window(wi, regs);
+        put_window(wi, regs);
+    }
+    __syncthreads();
+    for (;;) {
+        const uint32_t w0 = wi * FLAT_STRIDE;
+        const uint32_t* win = wins[wi & 1];
+        u32x4 next[FLAT_WIN_LOADS];
+        load_window(wi + 1, next);
         if (tid < 64) {
             uint32_t pos = st.pos, found = st.found, guess = st.guess, alt = st.alt, rounds = st.rounds;
             bool good_walk = true, done = false;
@@ -1094,8 +1113,10 @@ __global__ __launch_bounds__(DT) void delta_flat_walk(const DevPage* __restrict_
                 st.done = done ? 1 : 0;
             }
         }
+        put_window(wi + 1, next); // the other buffer: nobody reads it during this walk
         __syncthreads();
         if (!st.ok || st.done) break;
+        wi++;
     }
     if (tid == 0) {
         if (st.ok && st.done) {
