@@ -948,9 +948,12 @@ __global__ __launch_bounds__(DT) void delta_decode_kernel(const DevPage* __restr
 // writers' usual geometry (blocks of 128 values, four miniblocks) are decoded here instead:
 //   delta_flat_walk   per page, finds where every block starts out of a 16 KB window of the
 //                     stream in LDS: lane l guesses that block l starts l * S bytes after the
-//                     first (S: the size most blocks have had), reads the sixteen bytes there,
-//                     and the guess holds for the lanes whose predecessors all measured S; 64
-//                     blocks per round when the widths are steady.  Anything unusual -- a
+//                     first (S: the size most blocks have had), reads the bytes around there,
+//                     and the guess holds for the lanes whose predecessors all measured S;
+//                     behind a block a few bytes longer or shorter (a min delta whose varint
+//                     grew) the lanes look again, moved by the difference, out of the bytes
+//                     they already hold.  64 blocks per round when the widths are steady.
+//                     Anything unusual -- a
 //                     header problem, a width over the value width, data cut short, sizes that
 //                     keep changing -- leaves the page to the kernels above, untouched.
 //   delta_flat_tile   a workgroup per tile of 1024 deltas (8 blocks), twice: first only the
@@ -970,7 +973,7 @@ constexpr uint32_t FLAT_WIN = FLAT_STRIDE + 64;    // ... and overlap by 64 byte
 constexpr uint32_t FLAT_WIN_LOADS = (FLAT_WIN + DT * 16 - 1) / (DT * 16);
 
 struct FlatWalkState {
-    uint32_t pos, found, guess, alt, rounds;
+    uint32_t pos, found, guess, alt, rounds, mark, again;
     int32_t ok, done;
 };
 
@@ -1024,7 +1027,7 @@ __global__ __launch_bounds__(DT) void delta_flat_walk(const DevPage* __restrict_
     const uint32_t mis = (uint32_t)((uintptr_t)(pg.src + src_skip) & 15);
     gptr<const uint8_t> base = src - mis;
     const uint32_t end = mis + (uint32_t)src_len;
-    if (tid == 0) { st.pos = mis + p; st.found = 0; st.guess = 0; st.alt = 0; st.rounds = 0; st.ok = 1; st.done = 0; }
+    if (tid == 0) { st.pos = mis + p; st.found = 0; st.guess = 0; st.alt = 0; st.rounds = 0; st.mark = 0; st.again = 0; st.ok = 1; st.done = 0; }
     __syncthreads();
     // Window i holds window-space bytes [i * FLAT_STRIDE, i * FLAT_STRIDE + FLAT_WIN); the walk goes
     // through the windows in order, and window i + 1 is on its way from memory while window i is walked.
@@ -1053,41 +1056,71 @@ __global__ __launch_bounds__(DT) void delta_flat_walk(const DevPage* __restrict_
         u32x4 next[FLAT_WIN_LOADS];
         load_window(wi + 1, next);
         if (tid < 64) {
-            uint32_t pos = st.pos, found = st.found, guess = st.guess, alt = st.alt, rounds = st.rounds;
+            uint32_t pos = st.pos, found = st.found, guess = st.guess, alt = st.alt, rounds = st.rounds, mark = st.mark, again = st.again;
             bool good_walk = true, done = false;
             const bool to_end = w0 + FLAT_WIN >= end; // the window reaches the end of the stream
             while (found < n_blocks) {
                 const uint32_t bidx = found + lane;
                 const uint64_t cand64 = (uint64_t)pos + (uint64_t)lane * guess;
-                const bool resident = cand64 + 16 <= (uint64_t)w0 + FLAT_WIN || (to_end && cand64 + 5 <= end);
+                const bool resident = cand64 + 24 <= (uint64_t)w0 + FLAT_WIN || (to_end && cand64 + 5 <= end);
                 if (!lane_u32((uint32_t)resident, 0)) break; // the next block lies past the window: move it
-                const uint32_t cand = (uint32_t)cand64;
+                uint32_t cand = (uint32_t)cand64;
+                const bool live = bidx < n_blocks && resident;
+                // 28 bytes from the dword boundary at or before cand - 4: room to look at the header a few
+                // bytes before or after the place the regular spacing says
+                const uint32_t back = live && cand >= w0 + 4 ? 4u : 0u;
+                const uint32_t rs = live ? cand - back - w0 : 0u, d = rs >> 2;
+                uint32_t x[7];
+#pragma unroll
+                for (int i = 0; i < 7; i++) x[i] = win[d + i];
+                int32_t shift = 0;      // this lane's block starts `shift` bytes after its candidate
                 uint32_t size = 0;
                 bool good = false;
-                if (bidx < n_blocks && resident && cand64 + 5 <= end) {
-                    const uint32_t at = cand - w0, d = at >> 2, sh8 = (at & 3) * 8;
-                    const uint32_t x0 = win[d], x1 = win[d + 1], x2 = win[d + 2], x3 = win[d + 3], x4 = win[d + 4];
-                    const uint64_t lo = ((uint64_t)__builtin_amdgcn_alignbit(x2, x1, sh8) << 32) | __builtin_amdgcn_alignbit(x1, x0, sh8);
-                    const uint64_t hi = ((uint64_t)__builtin_amdgcn_alignbit(x4, x3, sh8) << 32) | __builtin_amdgcn_alignbit(x3, x2, sh8);
-                    uint32_t k, wd;
-                    if (quick_header(lo, hi, k, wd)) {
-                        const uint32_t bvals = n_deltas - bidx * 128 < 128 ? n_deltas - bidx * 128 : 128;
-                        const uint32_t need = (bvals + 31) / 32;
-                        uint32_t bits = 0, top = 0;
-                        for (uint32_t m = 0; m < need; m++) {
-                            const uint32_t bw = (wd >> (8 * m)) & 0xff;
-                            bits += bw;
-                            top = bw > top ? bw : top;
+                uint32_t from = 0;      // lanes from here on are (re)parsed
+                uint32_t valid = 0;
+                for (int pass = 0; pass < 16; pass++) {
+                    if (lane >= from) {
+                        size = 0;
+                        good = false;
+                        const int32_t o = (int32_t)((rs & 3) + back) + shift;   // header's byte offset in x[]
+                        if (live && o >= 0 && o <= 11 && (uint64_t)cand + shift + 5 <= end) {
+                            const uint32_t q = (uint32_t)o >> 2, sh8 = ((uint32_t)o & 3) * 8;
+                            const uint32_t a0 = q == 0 ? x[0] : (q == 1 ? x[1] : x[2]), a1 = q == 0 ? x[1] : (q == 1 ? x[2] : x[3]),
+                                           a2 = q == 0 ? x[2] : (q == 1 ? x[3] : x[4]), a3 = q == 0 ? x[3] : (q == 1 ? x[4] : x[5]),
+                                           a4 = q == 0 ? x[4] : (q == 1 ? x[5] : x[6]);
+                            const uint64_t lo = ((uint64_t)__builtin_amdgcn_alignbit(a2, a1, sh8) << 32) | __builtin_amdgcn_alignbit(a1, a0, sh8);
+                            const uint64_t hi = ((uint64_t)__builtin_amdgcn_alignbit(a4, a3, sh8) << 32) | __builtin_amdgcn_alignbit(a3, a2, sh8);
+                            uint32_t k, wd;
+                            if (quick_header(lo, hi, k, wd)) {
+                                const uint32_t bvals = n_deltas - bidx * 128 < 128 ? n_deltas - bidx * 128 : 128;
+                                const uint32_t need = (bvals + 31) / 32;
+                                uint32_t bits = 0, top = 0;
+                                for (uint32_t m = 0; m < need; m++) {
+                                    const uint32_t bw = (wd >> (8 * m)) & 0xff;
+                                    bits += bw;
+                                    top = bw > top ? bw : top;
+                                }
+                                size = k + 4 + 4 * bits;
+                                // a miniblock cut short is zero padded by the reference: not on this path
+                                good = top <= Elem<U>::max_bw && (uint64_t)cand + shift + size <= end;
+                            }
                         }
-                        size = k + 4 + 4 * bits;
-                        // a miniblock cut short is zero padded by the reference: not on this path
-                        good = top <= Elem<U>::max_bw && (uint64_t)cand + size <= end;
                     }
+                    // lanes up to the first whose block is not of the usual size stand where the stream has them
+                    const unsigned long long goodmask = __ballot(good);
+                    const unsigned long long same = __ballot(good && size == guess) | ((1ull << from) - 1);
+                    const uint32_t lead = same == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~same);
+                    if (lead >= 64) { valid = 64; break; }
+                    if (!((goodmask >> lead) & 1)) { valid = lead; break; }
+                    // that block is a true one of another size: the lanes after it look again, moved by the difference
+                    const int32_t moved = lane_u32((uint32_t)shift, lead) + (int32_t)lane_u32(size, lead) - (int32_t)guess;
+                    valid = lead + 1;
+                    if (guess == 0 || moved < -4 || moved > 4 || lead == 63) break;
+                    if (lane > lead) shift = moved;
+                    from = lead + 1;
+                    again++;
                 }
-                const unsigned long long goodmask = __ballot(good);
-                const unsigned long long same = __ballot(good && size == guess);
-                const uint32_t lead = same == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~same);
-                uint32_t valid = lead < 64 ? lead + (uint32_t)((goodmask >> lead) & 1) : 64u;
+                cand = (uint32_t)((int32_t)cand + shift);
                 if (valid > n_blocks - found) valid = n_blocks - found;
                 if (valid == 0) { good_walk = false; break; }
                 if (lane < valid) pos_out[bidx] = cand - mis;
@@ -1095,20 +1128,34 @@ __global__ __launch_bounds__(DT) void delta_flat_walk(const DevPage* __restrict_
                 const uint32_t l_size = lane_u32(size, last);
                 pos = lane_u32(cand, last) + l_size;
                 found += valid;
-                // the size most blocks have stays the guess: an odd one is adopted only when it comes twice in a row
+                // The size most blocks have stays the guess.  Another one is adopted when the last two
+                // blocks of a round agree on it, or when a round of one block meets it twice in a row.
                 if (l_size != guess) {
-                    if (guess == 0 || l_size == alt) guess = l_size;
-                    alt = l_size;
+                    const uint32_t before = valid >= 2 ? lane_u32(size, valid - 2) : alt;
+                    if (guess == 0 || before == l_size) guess = l_size;
+                    alt = valid >= 2 ? 0u : l_size;
+                } else {
+                    alt = 0;
                 }
-                rounds++;
                 // Block sizes that keep changing make this walk slower than decoding the page the
-                // usual way (a round is a dependent chain of LDS reads and cross-lane moves, about
-                // half a microsecond): give up early, before much is spent.
-                if (rounds >= 4 && found < rounds * 16 && found < n_blocks) { good_walk = false; break; }
+                // usual way (a round is a dependent chain of LDS reads and cross-lane moves, half a
+                // microsecond and more).  Rounds that end for another reason than the window's or the
+                // page's end are counted, and every four of them must have brought 16 blocks.
+                // every block of another size costs a pass of its own: with more than one in four the page is
+                // decoded sooner the usual way
+                // wide blocks: few fit a window, the walk crawls, and the page-per-workgroup kernel is at its best
+                if (guess > 640) { good_walk = false; break; }
+                const bool early = found <= 256; // the verdict on a page's regularity is reached at its start: giving up late wastes the walk so far
+                if (early && again > 8 + found / 4) { good_walk = false; break; }
+                const bool cut_short = valid < 64 && found < n_blocks && lane_u32((uint32_t)resident, valid) != 0;
+                if (cut_short && (++rounds & 3) == 0) {
+                    if (early && found < mark + 16) { good_walk = false; break; }
+                    mark = found;
+                }
             }
             if (found == n_blocks && good_walk) done = true;
             if (tid == 0) {
-                st.pos = pos; st.found = found; st.guess = guess; st.alt = alt; st.rounds = rounds;
+                st.pos = pos; st.found = found; st.guess = guess; st.alt = alt; st.rounds = rounds; st.mark = mark; st.again = again;
                 st.ok = good_walk ? 1 : 0;
                 st.done = done ? 1 : 0;
             }
