@@ -273,3 +273,20 @@ def test_few_pages_length_streams_chain():
         assert out.status == 0 and out.out_values == n and out.consumed == want.consumed
         assert out.data.tobytes() == b"".join(vals)
         assert np.array_equal(out.offsets[: n + 1], want.offsets)
+
+
+def test_few_pages_min_delta_varint_flips():
+    # deltas uniform below 2^w: the block's min delta sits near a varint length boundary, so one block
+    # in a few is a byte longer or shorter than its neighbours (and for wide w the walk declines the page)
+    P = pkg()
+    rng = np.random.default_rng(44)
+    c64, c32 = [], []
+    for bw in (6, 7, 12, 13, 14, 16, 20, 21, 24, 28, 32, 40, 48, 63):
+        for n in (5000, 131072):
+            d = rng.integers(0, 1 << bw, size=n, dtype=np.uint64)
+            c64.append((f"i64-w{bw}-n{n}", O.delta_encode_int64(np.cumsum(d, dtype=np.uint64).view(np.int64)), (bw + n) % 16))
+            if bw <= 28:
+                v32 = (np.cumsum(d, dtype=np.uint64) & 0xffffffff).astype(np.uint32).view(np.int32)
+                c32.append((f"i32-w{bw}-n{n}", O.delta_encode_int32(v32), (bw + 7) % 16))
+    _few(c64, P.KIND.INT64, np.int64, O.delta_decode_int64)
+    _few(c32, P.KIND.INT32, np.int32, O.delta_decode_int32)
