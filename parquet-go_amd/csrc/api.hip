@@ -211,8 +211,16 @@ int pqd_ctx_create(int device, pqd_ctx** out) {
     pqd_ctx* ctx = new (std::nothrow) pqd_ctx;
     if (ctx == nullptr) return PQD_ERR_DEVICE;
     ctx->device = device;
-    for (hipStream_t& st : ctx->side)
-        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
+    // Side streams for the kernel families of a small batch are an option (PQD_SIDE_BY_SIDE=1): they
+    // gain a single-stream caller a few per cent, but every batch of the context goes through the same
+    // three, which ties together batches that a caller launched on streams of its own -- and those
+    // overlap far better when left alone.
+    const char* opt = getenv("PQD_SIDE_BY_SIDE");
+    const bool side_by_side = opt != nullptr && opt[0] == '1';
+    for (hipStream_t& st : ctx->side) {
+        st = nullptr;
+        if (side_by_side && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
+    }
     *out = ctx;
     return PQD_OK;
 }

@@ -448,3 +448,32 @@ def test_delta_byte_array_random_length_streams():
         want = O.dba_decode(enc)
         assert want.status == 0, k
         _same_byte_array(out, want, f"random streams {k}")
+
+
+def test_mixed_batch_on_side_streams(monkeypatch):
+    # PQD_SIDE_BY_SIDE=1: a context whose small batches fork their kernel families onto side streams
+    P = pkg()
+    from parquet_go_amd.runtime import decode_pages
+    monkeypatch.setenv("PQD_SIDE_BY_SIDE", "1")
+    side_ctx = P.Context(0)
+    monkeypatch.delenv("PQD_SIDE_BY_SIDE")
+    rng = np.random.default_rng(13)
+    ints = np.cumsum(rng.integers(0, 1000, size=40000, dtype=np.int64))
+    strs = _urls(rng, 3000)
+    lv = rng.integers(0, 4, size=50000, dtype=np.uint8)
+    f64 = rng.standard_normal(30000)
+    specs = [
+        spec(P.ENC.DELTA_BINARY_PACKED, P.KIND.INT64, O.delta_encode_int64(ints)),
+        spec(P.ENC.RLE, P.KIND.LEVELS, O.rle_encode_levels(lv, 2), bit_width=2),
+        spec(P.ENC.BYTE_STREAM_SPLIT, P.KIND.DOUBLE, O.bss_encode(f64.tobytes(), 8)),
+        spec(P.ENC.PLAIN, P.KIND.BYTE_ARRAY, O.plain_encode_byte_array(strs)),
+        spec(P.ENC.DELTA_BYTE_ARRAY, P.KIND.BYTE_ARRAY, O.dba_encode(strs)),
+    ]
+    for _ in range(3):
+        outs = decode_pages(side_ctx, specs)
+        assert all(o.status == 0 for o in outs), [o.status for o in outs]
+        assert np.array_equal(outs[0].data.view(np.int64), ints)
+        assert np.array_equal(outs[1].data[:50000], lv)
+        assert outs[2].data.tobytes() == f64.tobytes()
+        assert outs[3].data.tobytes() == b"".join(strs) and outs[4].data.tobytes() == b"".join(strs)
+    side_ctx.close()
