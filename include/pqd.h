@@ -41,7 +41,11 @@ const char* pqd_status_name(int status);
 
 /* Binds the library to a HIP device.  Safe to call from several threads;
  * contexts are independent ("Encoding instances must be safe to use
- * concurrently", encoding/encoding.go:19). */
+ * concurrently", encoding/encoding.go:19).  With PQD_SIDE_BY_SIDE=1 in the
+ * environment the context owns three side streams, and a batch of at most 1024
+ * items forks its kernel families onto them: worth it for a caller that
+ * launches small batches on one stream, a loss for one that already deals
+ * them to several streams (all batches of a context share the side streams). */
 int pqd_ctx_create(int device, pqd_ctx** out);
 void pqd_ctx_destroy(pqd_ctx* ctx);
 

@@ -12,7 +12,8 @@
  *  - plain.DecodeByteArray compares a length against the whole input, not the
  *    remainder (encoding/plain/plain.go:84); here an overrunning value is
  *    UNEXPECTED_EOF.
- *  - DELTA miniblock widths above the value width are handed by the reference
+ *  - DELTA miniblock widths above the value width (of miniblocks that hold
+ *    values) are handed by the reference
  *    to the external bitpack.Unpack, whose behaviour there is not pinned by
  *    anything in the reference; here they are INVALID_BIT_WIDTH.
  *  - PLAIN FIXED_LEN_BYTE_ARRAY with size 0 divides by zero in the reference
@@ -377,7 +378,8 @@ static pqo_result delta_decode(void* dstv, uint64_t cap_bytes, const uint8_t* sr
             uint32_t bw = widths[m];
             uint64_t nv = vpm < remaining ? vpm : remaining;
             if (bw != 0) {
-                if (bw > max_bw) { r.consumed = i; return fail(r, PQD_ERR_INVALID_BIT_WIDTH, bw); }
+                /* a miniblock of no values (more miniblocks than values per block) unpacks nothing: its width goes unexamined */
+                if (bw > max_bw && nv > 0) { r.consumed = i; return fail(r, PQD_ERR_INVALID_BIT_WIDTH, bw); }
                 uint64_t mbsize = vpm * bw / 8;
                 uint64_t avail = mbsize <= n - i ? mbsize : n - i;
                 for (uint64_t v = 0; v < nv; v++) {

@@ -174,8 +174,11 @@ def test_errors_and_truncation():
         ("min-delta-overflow", bytes([0x80, 0x01, 0x04, 0x05, 0x02]) + b"\x80" * 11, 10),
         ("short-widths", bytes([0x80, 0x01, 0x04, 0x40, 0x02, 0x02, 0x03]), 11),
         ("more-miniblocks-than-values", bytes([0x80, 0x01, 0x80, 0x02, 0x05, 0x00]) + b"\x00" * 700, 12),
+        # ... whose miniblocks hold no values, so that their widths (any byte) unpack nothing: "4 missing values"
+        ("empty-miniblocks-any-width", bytes([0x80, 0x01, 0x80, 0x02, 0x05, 0x00]) + bytes(range(256)) * 3, 13),
     ]
     _run(cases, P.KIND.INT64, np.int64, O.delta_decode_int64)
+    _run([(label, src, mis) for label, src, mis in cases[-2:]], P.KIND.INT32, np.int32, O.delta_decode_int32)
     # a width above the value width: status only (the reference hands it to bitpack.Unpack)
     bad = bytearray(O.delta_encode_int64(np.arange(300, dtype=np.int64)))
     hdr = 5 if bad[3] < 0x80 else 6

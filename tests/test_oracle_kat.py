@@ -353,6 +353,11 @@ def test_error_statuses():
     full = O.delta_encode_int64(np.arange(0, 40, dtype=np.int64) ** 2)
     r = E.delta_decode_int64(full[:-3])
     assert r.status == 0 and r.n_values == 40
+    # 256 miniblocks in a block of 128: the miniblocks hold no values (128 / 256 = 0, and 0 % 32 == 0 passes
+    # binary_packed.go:443), every block yields nothing, the loop ends with the input: "4 missing values"
+    # (binary_packed.go:367-404); widths of miniblocks that unpack nothing are not looked at
+    r = E.delta_decode_int64(bytes([0x80, 0x01, 0x80, 0x02, 0x05, 0x00]) + bytes(range(256)) * 3)
+    assert r.status == 9 and r.arg == 4
     # BSS / PLAIN size checks
     assert E.bss_decode(b"12345", 4).status == 2
     assert E.bss_decode(b"1234", 0, is_flba=True).status == 2
