@@ -95,9 +95,26 @@ def runs(rng, n, top):
 
 def make_page(rng, P):
     """(label, spec arguments, checker call) of one random page."""
-    n = int(rng.choice([0, 1, 2, 7, 64, 127, 128, 129, 1000, 5000, 20000, 60000]))
+    n = int(rng.choice([0, 1, 2, 7, 64, 127, 128, 129, 1000, 5000, 20000, 60000, 400000]))
     n = int(rng.integers(0, n + 1)) if rng.integers(0, 2) else n
-    which = int(rng.integers(0, 14))
+    which = int(rng.integers(0, 16))
+    if which >= 14:
+        # dictionary indexes looked up as they are unpacked (newIndexedPage + Dictionary.Lookup): the stream may be
+        # shorter or longer than the page's value count, and an index may lie outside the dictionary
+        dn = int(rng.choice([1, 2, 10, 300, 5000, 70000]))
+        dt, kind = [(np.int64, P.KIND.INT64), (np.int32, P.KIND.INT32), (np.float64, P.KIND.DOUBLE)][int(rng.integers(0, 3))]
+        d = rng.integers(-2**31, 2**31 - 1, size=dn).astype(dt)
+        top = dn - 1 if rng.integers(0, 8) else dn + 3
+        v = runs(rng, n, top).astype(np.int32)
+        nv = int(rng.choice([-1, n, n, max(n - 5, 0), n + 9]))
+
+        def check_fused(src, d=d, nv=nv):
+            r = O.rle_dict_decode_int32(src)
+            if r.status != 0:
+                return r
+            return O.dict_lookup(d, O.indexed_page_fixup(r.values, nv) if nv >= 0 else r.values)
+        return f"dict{dn}-{np.dtype(dt).name}-nv{nv}", dict(encoding=P.ENC.RLE_DICTIONARY, kind=kind, dictionary=d, num_values=nv), \
+            O.rle_dict_encode_int32(v), check_fused, np.uint8
     if which == 0:
         v = np.cumsum(deltas(rng, n, 40))
         enc = O.delta_encode_int64(v)
@@ -231,7 +248,7 @@ def main():
                 os.makedirs("gpurun_out", exist_ok=True)
                 with open(name, "wb") as f:
                     f.write(src)
-                print(f"DIFF {label} {args}: {bad} -> {name}", flush=True)
+                print(f"DIFF {label} { {k: v for k, v in args.items() if k != 'dictionary'} }: {bad} -> {name}", flush=True)
         if rounds % 20 == 0:
             print(f"... {pages} pages, {diffs} differences, {skipped} too large to compare", flush=True)
     print(f"soak seed {seed}: {pages} pages in {rounds} batches, {diffs} differences, {skipped} too large to compare; "
