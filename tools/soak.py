@@ -97,7 +97,17 @@ def make_page(rng, P):
     """(label, spec arguments, checker call) of one random page."""
     n = int(rng.choice([0, 1, 2, 7, 64, 127, 128, 129, 1000, 5000, 20000, 60000, 400000]))
     n = int(rng.integers(0, n + 1)) if rng.integers(0, 2) else n
-    which = int(rng.integers(0, 16))
+    which = int(rng.integers(0, 18))
+    if which >= 16:
+        # one width for the whole page, the odd narrower miniblock aside: the shape the tile-parallel DELTA kernels take
+        w = int(rng.integers(0, 34))
+        d = rng.integers(0, 1 << w, size=n, dtype=np.int64) + int(rng.integers(-70, 70))
+        if which == 16:
+            return f"delta64-steady-w{w}", dict(encoding=P.ENC.DELTA_BINARY_PACKED, kind=P.KIND.INT64), \
+                O.delta_encode_int64(np.cumsum(d)), O.delta_decode_int64, np.int64
+        d = rng.integers(0, 1 << min(w, 12), size=n, dtype=np.int64) + int(rng.integers(-70, 70))
+        return f"delta32-steady-w{min(w, 12)}", dict(encoding=P.ENC.DELTA_BINARY_PACKED, kind=P.KIND.INT32), \
+            O.delta_encode_int32(np.cumsum(d).astype(np.int32)), O.delta_decode_int32, np.int32
     if which >= 14:
         # dictionary indexes looked up as they are unpacked (newIndexedPage + Dictionary.Lookup): the stream may be
         # shorter or longer than the page's value count, and an index may lie outside the dictionary
