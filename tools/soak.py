@@ -93,11 +93,12 @@ def runs(rng, n, top):
     return out
 
 
-def make_page(rng, P):
+def make_page(rng, P, only=None, n_max=400000):
     """(label, spec arguments, checker call) of one random page."""
     n = int(rng.choice([0, 1, 2, 7, 64, 127, 128, 129, 1000, 5000, 20000, 60000, 400000]))
+    n = min(n, n_max)
     n = int(rng.integers(0, n + 1)) if rng.integers(0, 2) else n
-    which = int(rng.integers(0, 18))
+    which = int(rng.integers(0, 18)) if only is None else int(rng.choice(only))
     if which >= 16:
         # one width for the whole page, the odd narrower miniblock aside: the shape the tile-parallel DELTA kernels take
         w = int(rng.integers(0, 34))
@@ -214,8 +215,10 @@ def main():
     while time.time() < t_end and diffs < 40:
         rounds += 1
         items = []
-        for k in range(48):
-            label, args, enc, check, dtype = make_page(rng, P)
+        # every fourth batch: 300 DELTA pages, above the page count up to which the tile-parallel kernels are tried
+        many = rounds % 4 == 0
+        for k in range(300 if many else 48):
+            label, args, enc, check, dtype = make_page(rng, P, (0, 1, 2, 16, 17), 20000) if many else make_page(rng, P)
             how, src = damage(rng, enc)
             items.append((f"{label}/{how}/n{len(src)}", args, src, check, dtype))
         specs = [PageSpec(src=src, misalign=int(rng.integers(0, 16)), **args) for _, args, src, _, _ in items]
