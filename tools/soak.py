@@ -4,6 +4,10 @@ checker in oracle/.  Every difference in status, status argument or decoded outp
 the exit code is the number of differences (capped).  Run on a GPU box:
 
     PQD_SOAK_SECONDS=60 python tools/soak.py [seed]
+
+With PQD_SOAK_HOST=1 the same pages go one at a time through the host entry points
+(pqd_decode_int64 and its like, by way of the codec objects of parquet-go_amd/encoding.py) instead
+of a batch of device pointers: the calls a cgo binding of encoding.Encoding makes.
 """
 import os
 import sys
@@ -269,5 +273,81 @@ def main():
     return min(diffs, 100)
 
 
+class _TooBig(Exception):
+    pass
+
+
+class _BoundedNumpy:
+    """numpy for the codec objects, with destinations above LIMIT refused: a damaged page may ask for terabytes."""
+
+    def __getattr__(self, name):
+        return getattr(np, name)
+
+    @staticmethod
+    def empty(shape, dtype=float):
+        if int(np.prod(shape)) * np.dtype(dtype).itemsize > LIMIT:
+            raise _TooBig()
+        return np.empty(shape, dtype)
+
+
+def main_host():
+    P = pkg()
+    from parquet_go_amd import encoding as E
+    E.np = _BoundedNumpy()
+    K = P.KIND
+    method = {K.LEVELS: "DecodeLevels", K.BOOLEAN: "DecodeBoolean", K.INT32: "DecodeInt32", K.INT64: "DecodeInt64",
+              K.INT96: "DecodeInt96", K.FLOAT: "DecodeFloat", K.DOUBLE: "DecodeDouble"}
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + float(os.environ.get("PQD_SOAK_SECONDS", "60"))
+    pages = diffs = skipped = 0
+    by_status = {}
+    while time.time() < t_end and diffs < 40:
+        label, args, enc, check, dtype = make_page(rng, P, tuple(range(14)) + (16, 17), 60000)
+        how, src = damage(rng, enc)
+        want = check(src)
+        if want.status in (P.STATUS.DST_TOO_SMALL, P.STATUS.OFFSETS_TOO_SMALL):
+            skipped += 1
+            continue
+        codec = E.LookupEncoding(args["encoding"])
+        codec.BitWidth = args.get("bit_width", 0)
+        status = arg = 0
+        values = offsets = None
+        try:
+            if args["kind"] == K.BYTE_ARRAY:
+                values, offsets = codec.DecodeByteArray(None, src, None)
+            else:
+                values = getattr(codec, method[args["kind"]])(None, src)
+        except _TooBig:
+            skipped += 1
+            continue
+        except E.EncodingError as e:
+            status, arg = e.status, e.arg
+        pages += 1
+        by_status[want.status] = by_status.get(want.status, 0) + 1
+        bad = None
+        if status != want.status:
+            bad = f"status {status} (arg {arg}) != {want.status} (arg {want.arg})"
+        elif status != 0 and arg != want.arg:
+            bad = f"status {status}: arg {arg} != {want.arg}"
+        elif status == 0:
+            if np.ascontiguousarray(values).tobytes() != np.ascontiguousarray(want.values).tobytes():
+                bad = f"values differ ({values.nbytes} / {want.values.nbytes} bytes)"
+            elif offsets is not None and not np.array_equal(offsets, want.offsets):
+                bad = f"offsets differ ({offsets.size} / {want.offsets.size})"
+        if bad:
+            diffs += 1
+            name = f"gpurun_out/soak_host_{seed}_{diffs}.bin"
+            os.makedirs("gpurun_out", exist_ok=True)
+            with open(name, "wb") as f:
+                f.write(src)
+            print(f"DIFF {label}/{how}/n{len(src)}: {bad} -> {name}", flush=True)
+        if pages % 1000 == 0:
+            print(f"... {pages} pages, {diffs} differences, {skipped} too large to compare", flush=True)
+    print(f"host soak seed {seed}: {pages} pages, one call each, {diffs} differences, {skipped} too large to compare; "
+          f"checker statuses {dict(sorted(by_status.items()))}")
+    return min(diffs, 100)
+
+
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(main_host() if os.environ.get("PQD_SOAK_HOST") == "1" else main())
