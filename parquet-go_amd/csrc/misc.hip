@@ -781,9 +781,10 @@ __global__ __launch_bounds__(WT) void dba_kernel(const DevPage* __restrict__ pag
 //                      decision whether the page takes this path (anything unusual -- an error,
 //                      FIXED_LEN_BYTE_ARRAY, very long values -- is left to dba_kernel, which
 //                      reports errors exactly as the sequential decoder does);
-//   dba_expand_kernel  per block, one wavefront, a lane per value: the bytes the block inherits
-//                      from earlier values are looked up by walking the least prefix lengths of
-//                      the blocks before it; the block's values are put together in an LDS image
+//   dba_expand_kernel  a wavefront per run of consecutive blocks, a lane per value: the bytes the
+//                      first block of the run inherits from earlier values are looked up by
+//                      walking the least prefix lengths of the blocks before it, those of the
+//                      other blocks are the last value the wavefront has just built; the block's values are put together in an LDS image
 //                      of its output bytes, dword column by dword column, the inherited bytes of
 //                      a column travelling from lane to lane in a segmented wave scan; the image
 //                      is copied out with aligned 16-byte stores.
@@ -947,18 +948,31 @@ __global__ __launch_bounds__(WT) void dba_expand_kernel(const DevPage* __restric
     uint32_t* img32 = reinterpret_cast<uint32_t*>(img);
     const uint32_t* carry32 = reinterpret_cast<const uint32_t*>(carry);
 
-    for (uint64_t blk = blockIdx.y; blk < nblk; blk += gridDim.y) {
+    // A wavefront takes blocks that follow one another: only for the first does it look the inherited
+    // bytes up in the blocks before; after that they are the last value of the image it has just built.
+    const uint64_t per = (nblk + gridDim.y - 1) / gridDim.y;
+    const uint64_t b_lo = blockIdx.y * per, b_hi = b_lo + per < nblk ? b_lo + per : nblk;
+    // lengths and sums of the block to come, asked for a block ahead
+    uint32_t p_n = 0, s_n = 0, bs_n = 0, bo_n = 0;
+    if (b_lo < b_hi) {
+        const uint64_t k0 = b_lo * DBLK + lane;
+        if (k0 < ns) { p_n = (uint32_t)prefix[k0]; s_n = (uint32_t)suffix[k0]; }
+        bs_n = bstat[3 * b_lo];
+        bo_n = bstat[3 * b_lo + 1];
+    }
+    for (uint64_t blk = b_lo; blk < b_hi; blk++) {
+        const bool inherited = blk != b_lo; // carry[] holds the value before this block
         const uint64_t k = blk * DBLK + lane;
         const bool valid = k < ns;
-        const uint32_t p = valid ? (uint32_t)prefix[k] : 0u, s = valid ? (uint32_t)suffix[k] : 0u;
+        const uint32_t p = p_n, s = s_n;
         const uint32_t len = p + s;
-        const uint32_t base_s = bstat[3 * blk], base_o = bstat[3 * blk + 1];
+        const uint32_t base_s = bs_n, base_o = bo_n;
         // Asked for now, used by the look-up of the inherited bytes below, so that it does not start
         // with two more trips to memory: the least prefix lengths of the 64 blocks before this one,
         // and the lengths of the block just before it (last value first).
-        const uint32_t bm0 = (uint64_t)lane < blk ? bstat[3 * (blk - 1 - lane) + 2] & ~DBIG : 0xffffffffu;
+        const uint32_t bm0 = !inherited && (uint64_t)lane < blk ? bstat[3 * (blk - 1 - lane) + 2] & ~DBIG : 0xffffffffu;
         uint32_t pj0 = 0, sj0 = 0;
-        if (blk > 0) {
+        if (blk > 0 && !inherited) {
             pj0 = (uint32_t)prefix[(blk - 1) * DBLK + (63 - lane)];
             sj0 = (uint32_t)suffix[(blk - 1) * DBLK + (63 - lane)];
         }
@@ -974,11 +988,18 @@ __global__ __launch_bounds__(WT) void dba_expand_kernel(const DevPage* __restric
         uint32_t w_first[3];
 #pragma unroll
         for (uint32_t u = 0; u < 3; u++) w_first[u] = 4 * u < s ? data_u32(data, (uint64_t)s_at + 4 * u, data_total) : 0u;
+        if (blk + 1 < b_hi) {
+            const uint64_t kn = k + DBLK;
+            p_n = kn < ns ? (uint32_t)prefix[kn] : 0u;
+            s_n = kn < ns ? (uint32_t)suffix[kn] : 0u;
+            bs_n = bstat[3 * (blk + 1)];
+            bo_n = bstat[3 * (blk + 1) + 1];
+        }
 
         // ---- what the block inherits: bytes [0, need) of the value before it ----
         const uint32_t need = lane_u32(p, 0);
         {
-            uint32_t r = need;     // bytes [0, r) are still to be found
+            uint32_t r = inherited ? 0u : need; // bytes [0, r) are still to be found
             uint64_t cur = blk;    // among the blocks before `cur`
             while (r > 0 && cur > 0) {
                 const bool have = (uint64_t)lane < cur;
@@ -1093,6 +1114,12 @@ __global__ __launch_bounds__(WT) void dba_expand_kernel(const DevPage* __restric
             for (uint32_t c = lane; c < body; c += WT)
                 *(gptr<u32x4>)(out + head + c * 16) = *reinterpret_cast<const u32x4*>(img + align + head + c * 16);
         }
+        // the block's last value, for the block after it
+        if (blk + 1 < b_hi) {
+            const uint32_t q_last = lane_u32(q, 63), len_last = lane_u32(len, 63);
+            const uint32_t nb = len_last < CARRY ? len_last : CARRY;
+            for (uint32_t c = lane * 4; c < nb; c += WT * 4) *reinterpret_cast<uint32_t*>(carry + c) = lds_u32(img32, q_last + c);
+        }
         wave_sync();
     }
 }
@@ -1164,9 +1191,9 @@ void launch_dba(const DevPage* pages, DevResult* results, const uint32_t* items,
     };
     hipLaunchKernelGGL(dba_block_kernel, dim3(n_items, slots((blocks + 15) / 16, 4096)), dim3(MT), 0, stream, pages, results, items);
     hipLaunchKernelGGL(dba_plan_kernel, dim3(n_items), dim3(MT), 0, stream, pages, results, items);
-    hipLaunchKernelGGL((dba_expand_kernel<DIMG_SMALL, DCARRY_SMALL, 1>), dim3(n_items, slots(blocks, 32768)), dim3(WT), 0, stream, pages,
+    hipLaunchKernelGGL((dba_expand_kernel<DIMG_SMALL, DCARRY_SMALL, 1>), dim3(n_items, slots(blocks, 16384)), dim3(WT), 0, stream, pages,
                        results, items);
-    hipLaunchKernelGGL((dba_expand_kernel<DIMG, DCARRY, 2>), dim3(n_items, slots(blocks, 32768)), dim3(WT), 0, stream, pages, results,
+    hipLaunchKernelGGL((dba_expand_kernel<DIMG, DCARRY, 2>), dim3(n_items, slots(blocks, 16384)), dim3(WT), 0, stream, pages, results,
                        items);
     hipLaunchKernelGGL(dba_kernel, dim3(n_items), dim3(WT), 0, stream, pages, results, items);
 }
