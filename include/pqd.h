@@ -258,7 +258,9 @@ typedef struct pqd_page_header {
  * found.  PQD_ERR_DST_TOO_SMALL when there are more than `cap`;
  * PQD_ERR_UNEXPECTED_EOF for a header or page cut short,
  * PQD_ERR_INVALID_ARGUMENT for negative sizes or counts (ErrCorrupted in the
- * reference); *status_arg = offset of the failing header. */
+ * reference), PQD_ERR_CHECKSUM when a header carries a CRC other than zero and
+ * the IEEE CRC-32 of the page bytes differs (FilePages.readPage,
+ * file.go:1455-1475); *status_arg = offset of the failing header. */
 int pqd_chunk_scan_pages(const uint8_t* chunk, uint64_t chunk_len, int64_t num_values, pqd_page_header* out,
                          uint64_t cap, uint64_t* n_pages, int64_t* status_arg);
 

@@ -66,7 +66,10 @@ typedef enum pqd_status {
     /* HIP runtime failure. arg = hipError_t */
     PQD_ERR_DEVICE = 17,
     /* offsets capacity too small. arg = entries needed */
-    PQD_ERR_OFFSETS_TOO_SMALL = 18
+    PQD_ERR_OFFSETS_TOO_SMALL = 18,
+    /* "crc32 checksum mismatch in page" (file.go:1455-1475; wraps ErrCorrupted).
+     * arg = offset of the page header in the chunk */
+    PQD_ERR_CHECKSUM = 19
 } pqd_status;
 
 /* Where an UNEXPECTED_EOF happened (status arg). */

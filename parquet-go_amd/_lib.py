@@ -38,6 +38,7 @@ class STATUS:
     DST_TOO_SMALL = 16
     DEVICE = 17
     OFFSETS_TOO_SMALL = 18
+    CHECKSUM = 19
 
 
 class ENC:

@@ -108,6 +108,7 @@ inline bool is_rle(int32_t family) { return rle_grid(family) >= 0; }
 
 int32_t classify(const pqd_page& p) {
     const int32_t e = p.encoding, k = p.kind;
+    if (k < PQD_KIND_LEVELS || k > PQD_KIND_FIXED_LEN_BYTE_ARRAY) return FAM_NONE;
     switch (e) {
         case PQD_ENC_DELTA_BINARY_PACKED:
             if (k == PQD_KIND_INT32) return FAM_DELTA32;
@@ -125,8 +126,12 @@ int32_t classify(const pqd_page& p) {
                     return FAM_RLE;
                 return FAM_NONE;
             }
-            if (k == PQD_KIND_INT32) return FAM_RLE;
-            return FAM_NONE;
+            // Without a dictionary the item stands for the codec object's own DecodeInt32:
+            // rle.DictionaryEncoding reads a width byte and hybrid runs (rle/dictionary.go:30-37),
+            // plain.DictionaryEncoding is a PLAIN decode of raw int32 (plain/dictionary.go:25-27; the
+            // rewrite of PLAIN_DICTIONARY data pages to RLE_DICTIONARY is the caller's, column.go:850-857).
+            if (k != PQD_KIND_INT32) return FAM_NONE;
+            return e == PQD_ENC_PLAIN_DICTIONARY ? FAM_PLAIN_FIXED : FAM_RLE;
         case PQD_ENC_BIT_PACKED:
             return k == PQD_KIND_LEVELS ? FAM_BITPACKED : FAM_NONE;
         case PQD_ENC_BYTE_STREAM_SPLIT:
@@ -198,6 +203,7 @@ const char* pqd_status_name(int status) {
         case PQD_ERR_DST_TOO_SMALL: return "DST_TOO_SMALL";
         case PQD_ERR_DEVICE: return "DEVICE";
         case PQD_ERR_OFFSETS_TOO_SMALL: return "OFFSETS_TOO_SMALL";
+        case PQD_ERR_CHECKSUM: return "CHECKSUM";
         default: return "UNKNOWN";
     }
 }
@@ -207,7 +213,8 @@ int pqd_ctx_create(int device, pqd_ctx** out) {
     *out = nullptr;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return PQD_ERR_DEVICE;
-    PQD_HIP(hipSetDevice(device));
+    DeviceGuard guard(device);
+    if (!guard.ok) return PQD_ERR_DEVICE;
     pqd_ctx* ctx = new (std::nothrow) pqd_ctx;
     if (ctx == nullptr) return PQD_ERR_DEVICE;
     ctx->device = device;
@@ -227,6 +234,7 @@ int pqd_ctx_create(int device, pqd_ctx** out) {
 
 void pqd_ctx_destroy(pqd_ctx* ctx) {
     if (ctx == nullptr) return;
+    DeviceGuard guard(ctx->device);
     for (hipStream_t st : ctx->side)
         if (st != nullptr) (void)hipStreamDestroy(st);
     delete ctx;
@@ -235,7 +243,8 @@ void pqd_ctx_destroy(pqd_ctx* ctx) {
 int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_batch** out) {
     if (ctx == nullptr || out == nullptr || (pages == nullptr && n_pages > 0)) return PQD_ERR_INVALID_ARGUMENT;
     *out = nullptr;
-    PQD_HIP(hipSetDevice(ctx->device));
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return PQD_ERR_DEVICE;
     pqd_batch* b = new (std::nothrow) pqd_batch;
     if (b == nullptr) return PQD_ERR_DEVICE;
     b->ctx = ctx;
@@ -250,7 +259,8 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
         int32_t family = classify(p);
         if (family == FAM_NONE) {
             m.host_status = PQD_ERR_NOT_SUPPORTED;
-        } else if ((p.src == nullptr && p.src_len > 0) || (p.dst == nullptr && p.dst_cap > 0)) {
+        } else if ((p.src == nullptr && p.src_len > 0) || (p.dst == nullptr && p.dst_cap > 0) ||
+                   (p.dict == nullptr && p.dict_len > 0)) {
             m.host_status = PQD_ERR_INVALID_ARGUMENT;
         } else if (family == FAM_DELTA32 || family == FAM_DELTA64) {
             m.primary = (int32_t)b->items.size();
@@ -258,7 +268,7 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
         } else if (is_rle(family)) {
             DevPage d = make_item(p, family);
             const bool dict_enc = p.encoding == PQD_ENC_RLE_DICTIONARY || p.encoding == PQD_ENC_PLAIN_DICTIONARY;
-            d.fused = (dict_enc && (p.dict != nullptr || p.dict_len > 0)) ? 1 : 0;
+            d.fused = (dict_enc && p.dict != nullptr) ? 1 : 0;
             if (!d.fused && dict_enc) d.elem_width = 4;
             if (d.fused && d.elem_width == 8) d.family = FAM_RLE_DICT8;
             if (d.fused && d.elem_width == 4) d.family = FAM_RLE_DICT4;
@@ -549,6 +559,8 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
 
 int pqd_batch_launch(pqd_batch* b, void* hip_stream) {
     if (b == nullptr) return PQD_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(b->ctx->device);
+    if (!guard.ok) return PQD_ERR_DEVICE;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     // The kernel families of a batch are independent of one another, except that the DELTA byte-array
     // families start from length streams the DELTA kernels decode.  A small batch runs them side by
@@ -592,6 +604,8 @@ int pqd_batch_launch(pqd_batch* b, void* hip_stream) {
 
 int pqd_batch_finish(pqd_batch* b, void* hip_stream, pqd_page* pages, uint64_t n_pages) {
     if (b == nullptr || (pages == nullptr && n_pages > 0) || n_pages != b->n_pages) return PQD_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(b->ctx->device);
+    if (!guard.ok) return PQD_ERR_DEVICE;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     PQD_HIP(hipStreamSynchronize(s));
     if (!b->items.empty())
@@ -623,6 +637,7 @@ int pqd_batch_finish(pqd_batch* b, void* hip_stream, pqd_page* pages, uint64_t n
 
 void pqd_batch_destroy(pqd_batch* b) {
     if (b == nullptr) return;
+    DeviceGuard guard(b->ctx->device);
     delete b;
 }
 

@@ -25,6 +25,7 @@ struct Compact {
     const uint8_t* end;
     bool ok = true;
     int depth = 0;
+    static constexpr int MAX_DEPTH = 32; // nested structs, lists, sets and maps
 
     uint8_t byte() {
         if (p >= end) { ok = false; return 0; }
@@ -59,19 +60,25 @@ struct Compact {
         case 4: case 5: case 6: (void)uvarint(); break;
         case 7: advance(8); break;
         case 8: advance(uvarint()); break;
+        // collections nest like structs do: the same depth limit, or a run of list headers
+        // (0x19 0x19 ...) would recurse once per byte
         case 9: case 10: {
+            if (++depth > MAX_DEPTH) { ok = false; return; }
             const uint8_t h = byte();
             uint64_t n = h >> 4;
             if (n == 15) n = uvarint();
             for (uint64_t i = 0; i < n && ok; i++) skip(h & 0xf, true);
+            depth--;
             break;
         }
         case 11: {
+            if (++depth > MAX_DEPTH) { ok = false; return; }
             const uint64_t n = uvarint();
             if (n > 0) {
                 const uint8_t kv = byte();
                 for (uint64_t i = 0; i < n && ok; i++) { skip(kv >> 4, true); skip(kv & 0xf, true); }
             }
+            depth--;
             break;
         }
         case 12: skip_struct(); break;
@@ -89,7 +96,7 @@ struct Compact {
         return ok;
     }
     void skip_struct() {
-        if (++depth > 32) { ok = false; return; }
+        if (++depth > MAX_DEPTH) { ok = false; return; }
         int id, type, last = 0;
         while (field(&id, &type, &last)) skip(type, false);
         depth--;
@@ -100,6 +107,40 @@ struct Compact {
         return (int32_t)zigzag();
     }
 };
+
+// crc32.ChecksumIEEE (polynomial 0xEDB88320, reflected), eight bytes per step.
+struct Crc32 {
+    uint32_t t[8][256];
+    Crc32() {
+        for (uint32_t i = 0; i < 256; i++) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; k++) c = (c >> 1) ^ (0xEDB88320u & (0u - (c & 1)));
+            t[0][i] = c;
+        }
+        for (uint32_t i = 0; i < 256; i++)
+            for (int k = 1; k < 8; k++) t[k][i] = (t[k - 1][i] >> 8) ^ t[0][t[k - 1][i] & 0xff];
+    }
+    uint32_t sum(const uint8_t* p, uint64_t n) const {
+        uint32_t c = 0xffffffffu;
+        while (n >= 8) {
+            uint32_t lo, hi;
+            memcpy(&lo, p, 4);
+            memcpy(&hi, p + 4, 4);
+            lo ^= c;
+            c = t[7][lo & 0xff] ^ t[6][(lo >> 8) & 0xff] ^ t[5][(lo >> 16) & 0xff] ^ t[4][lo >> 24] ^
+                t[3][hi & 0xff] ^ t[2][(hi >> 8) & 0xff] ^ t[1][(hi >> 16) & 0xff] ^ t[0][hi >> 24];
+            p += 8;
+            n -= 8;
+        }
+        while (n--) c = (c >> 8) ^ t[0][(c ^ *p++) & 0xff];
+        return ~c;
+    }
+};
+
+const Crc32& crc32_table() {
+    static const Crc32 table;
+    return table;
+}
 
 int32_t bits_len8(int32_t v) { // bits.Len8
     int32_t n = 0;
@@ -177,6 +218,14 @@ int pqd_chunk_scan_pages(const uint8_t* chunk, uint64_t chunk_len, int64_t num_v
             if (status_arg) *status_arg = (int64_t)pos;
             *n_pages = count;
             return negative ? PQD_ERR_INVALID_ARGUMENT : PQD_ERR_UNEXPECTED_EOF;
+        }
+        // FilePages.readPage (file.go:1455-1475): a checksum other than zero is compared with
+        // the IEEE CRC-32 of the page bytes as stored (compressed or not)
+        if (h.has_crc && h.crc != 0 &&
+            crc32_table().sum(chunk + h.data_offset, (uint64_t)h.compressed_page_size) != (uint32_t)h.crc) {
+            if (status_arg) *status_arg = (int64_t)pos;
+            *n_pages = count;
+            return PQD_ERR_CHECKSUM;
         }
         if (count < cap) out[count] = h;
         count++;

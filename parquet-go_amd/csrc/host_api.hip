@@ -83,7 +83,8 @@ int decode_host(pqd_ctx* ctx, int encoding, int kind, int bit_width, const uint8
     if (out_offsets) *out_offsets = 0;
     if (status_arg) *status_arg = 0;
     if (ctx == nullptr || (src == nullptr && src_len > 0) || (dst == nullptr && dst_cap > 0)) return PQD_ERR_INVALID_ARGUMENT;
-    if (hipSetDevice(ctx->device) != hipSuccess) return PQD_ERR_DEVICE;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return PQD_ERR_DEVICE;
     DevMem dsrc, ddst, doff;
     // 16 spare bytes so the kernels' aligned 16-byte loads of the last bytes stay inside the allocation
     if (!dsrc.alloc(src_len + 32) || !ddst.alloc(dst_cap + 32) || !doff.alloc(offsets_cap * 4 + 32)) return PQD_ERR_DEVICE;
@@ -170,7 +171,8 @@ int64_t pqd_estimate_decode_byte_array_size(pqd_ctx* ctx, int encoding, const ui
     if (encoding == PQD_ENC_PLAIN) return (int64_t)src_len;
     if (encoding != PQD_ENC_DELTA_LENGTH_BYTE_ARRAY && encoding != PQD_ENC_DELTA_BYTE_ARRAY) return 0;
     if (ctx == nullptr || (src == nullptr && src_len > 0)) return 0;
-    if (hipSetDevice(ctx->device) != hipSuccess) return 0;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return 0;
     DevMem dsrc, dsum;
     if (!dsrc.alloc(src_len + 32) || !dsum.alloc(16)) return 0;
     if (src_len && hipMemcpy(dsrc.p, src, src_len, hipMemcpyHostToDevice) != hipSuccess) return 0;
@@ -214,7 +216,8 @@ int pqd_dict_create(pqd_ctx* ctx, const void* values, uint64_t n, uint32_t width
     if (ctx == nullptr || out == nullptr || (values == nullptr && n > 0)) return PQD_ERR_INVALID_ARGUMENT;
     if (width != 4 && width != 8 && width != 12) return PQD_ERR_INVALID_ARGUMENT;
     *out = nullptr;
-    if (hipSetDevice(ctx->device) != hipSuccess) return PQD_ERR_DEVICE;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return PQD_ERR_DEVICE;
     pqd_dict* d = new (std::nothrow) pqd_dict;
     if (d == nullptr) return PQD_ERR_DEVICE;
     d->ctx = ctx; d->n = n; d->width = width; d->values = nullptr;
@@ -228,6 +231,7 @@ int pqd_dict_create(pqd_ctx* ctx, const void* values, uint64_t n, uint32_t width
 
 void pqd_dict_destroy(pqd_dict* d) {
     if (d == nullptr) return;
+    DeviceGuard guard(d->ctx->device);
     if (d->values) (void)hipFree(d->values);
     delete d;
 }
@@ -235,6 +239,8 @@ void pqd_dict_destroy(pqd_dict* d) {
 int pqd_dict_lookup_device(pqd_ctx* ctx, const void* dict_dev, uint64_t dict_len, uint32_t width, const int32_t* indexes_dev,
                            uint64_t n, void* rows_dev, uint64_t stride, int64_t* status_dev, void* hip_stream) {
     if (ctx == nullptr || status_dev == nullptr) return PQD_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return PQD_ERR_DEVICE;
     return launch_dict_gather(dict_dev, dict_len, width, indexes_dev, n, rows_dev, stride, status_dev,
                               static_cast<hipStream_t>(hip_stream));
 }
@@ -244,7 +250,8 @@ int pqd_dict_lookup(pqd_dict* d, const int32_t* indexes, uint64_t n, void* rows,
     if (d == nullptr || (indexes == nullptr && n > 0) || (rows == nullptr && n > 0)) return PQD_ERR_INVALID_ARGUMENT;
     if (stride == 0) stride = d->width;
     if (stride < d->width) return PQD_ERR_INVALID_ARGUMENT;
-    if (hipSetDevice(d->ctx->device) != hipSuccess) return PQD_ERR_DEVICE;
+    DeviceGuard guard(d->ctx->device);
+    if (!guard.ok) return PQD_ERR_DEVICE;
     DevMem didx, drows, dst;
     if (!didx.alloc(n * 4) || !drows.alloc(n * d->width) || !dst.alloc(16)) return PQD_ERR_DEVICE;
     if (n && hipMemcpy(didx.p, indexes, n * 4, hipMemcpyHostToDevice) != hipSuccess) return PQD_ERR_DEVICE;

@@ -254,6 +254,8 @@ uint64_t pqd_levels_workspace_size(uint64_t n_levels) { return (stretches_of(n_l
 int pqd_levels_count_equal_device(pqd_ctx* ctx, const uint8_t* levels_dev, uint64_t n, uint8_t value, void* workspace_dev,
                                   uint64_t workspace_bytes, uint64_t* count_dev, void* hip_stream) {
     if (ctx == nullptr || count_dev == nullptr || (levels_dev == nullptr && n > 0)) return PQD_ERR_INVALID_ARGUMENT;
+    pqd::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return PQD_ERR_DEVICE;
     if (!count_and_scan(levels_dev, n, value, workspace_dev, workspace_bytes, count_dev, static_cast<hipStream_t>(hip_stream)))
         return PQD_ERR_INVALID_ARGUMENT;
     return hipGetLastError() == hipSuccess ? PQD_OK : PQD_ERR_DEVICE;
@@ -267,6 +269,8 @@ int pqd_optional_expand_device(pqd_ctx* ctx, const uint8_t* def_levels_dev, uint
         (dst_dev == nullptr && n_slots > 0) || (values_dev == nullptr && n_values > 0))
         return PQD_ERR_INVALID_ARGUMENT;
     if (offsets_mode && (width != 4 || values_dev == nullptr || dst_dev == nullptr)) return PQD_ERR_INVALID_ARGUMENT;
+    pqd::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return PQD_ERR_DEVICE;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     if (!count_and_scan(def_levels_dev, n_slots, max_definition_level, workspace_dev, workspace_bytes, nullptr, s))
         return PQD_ERR_INVALID_ARGUMENT;
@@ -302,6 +306,8 @@ int pqd_repeated_row_starts_device(pqd_ctx* ctx, const uint8_t* rep_levels_dev, 
                                    void* workspace_dev, uint64_t workspace_bytes, int64_t* info_dev, void* hip_stream) {
     if (ctx == nullptr || info_dev == nullptr || (rep_levels_dev == nullptr && n > 0) || (row_starts_dev == nullptr && row_cap > 0))
         return PQD_ERR_INVALID_ARGUMENT;
+    pqd::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return PQD_ERR_DEVICE;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     if (!count_and_scan(rep_levels_dev, n, 0, workspace_dev, workspace_bytes, nullptr, s)) return PQD_ERR_INVALID_ARGUMENT;
     const uint64_t ns = stretches_of(n);

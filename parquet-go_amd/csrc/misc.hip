@@ -139,7 +139,7 @@ __device__ inline int32_t fixed_width(const DevPage& pg) {
 // (bytestreamsplit.go:35-105, plain.go:65-74,96-104).  Returns the value count.
 __device__ inline bool fixed_checks(const DevPage& pg, DevResult* res, bool lead, int32_t width, uint64_t* count) {
     const uint64_t n = pg.src_len;
-    if (pg.kind == PQD_KIND_FIXED_LEN_BYTE_ARRAY && (width <= 0 || (uint32_t)width > MAX_FLBA)) {
+    if (width <= 0 || (pg.kind == PQD_KIND_FIXED_LEN_BYTE_ARRAY && (uint32_t)width > MAX_FLBA)) {
         if (lead) finish(res, PQD_ERR_INVALID_ARGUMENT, width, 0, 0, 0);
         return false;
     }

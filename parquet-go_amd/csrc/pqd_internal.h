@@ -21,6 +21,25 @@ struct pqd_dict {
 
 namespace pqd {
 
+// Makes a context's device the calling thread's current device for the length of an entry
+// point and puts the caller's back afterwards: a process that drives several GPUs from
+// threads that move between them must not launch on, or allocate from, whichever device
+// the thread happened to use last.
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = false;
+    explicit DeviceGuard(int device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        ok = prev == device || hipSetDevice(device) == hipSuccess;
+        if (prev == device) prev = -1; // nothing to restore
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 // One entry of a run table built by the RLE index kernel.
 struct Run {
     uint32_t out_start;  // first output value of the run

@@ -746,8 +746,11 @@ struct EShared {
 __device__ inline uint64_t output_count(const DevPage& pg, uint64_t total, bool fused) {
     if (pg.num_values < 0) return total;
     uint64_t nv = (uint64_t)pg.num_values;
-    if (fused) return nv;            // short streams are zero-extended
-    return total < nv ? total : nv;  // longer streams are cut
+    // the indexes of a dictionary-encoded page are cut to num_values or zero-extended to it
+    // (newIndexedPage), whether they go on through the dictionary or are returned as they are
+    const bool indexes = pg.encoding == PQD_ENC_RLE_DICTIONARY || pg.encoding == PQD_ENC_PLAIN_DICTIONARY;
+    if (fused || indexes) return nv;
+    return total < nv ? total : nv;  // levels and plain RLE values are only ever cut (column.go:940-945)
 }
 
 template <int ELEM, bool FUSED>
@@ -1012,8 +1015,8 @@ __device__ inline void expand_tile(EShared& sh, const DevPage& pg, DevResult* re
             }
         }
     }
-    // zero-extended tail of a dictionary page
-    if (FUSED) {
+    // zero-extended tail of a dictionary page (n > n_stream only there: see output_count)
+    if (FUSED || ELEM == 4) {
         for (uint32_t j = n_stream + tid; j < n; j += ET) store_value<ELEM, FUSED>(pg, res, t0 + j, 0u, stride);
     }
 }

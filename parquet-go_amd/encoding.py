@@ -252,7 +252,9 @@ class RLEDictionary(Encoding):
 
 
 class PlainDictionary(Encoding):
-    """plain.DictionaryEncoding (encoding/plain/dictionary.go:9-27): the legacy name of RLE_DICTIONARY data pages."""
+    """plain.DictionaryEncoding (encoding/plain/dictionary.go:9-27): DecodeInt32 is a PLAIN decode of raw
+    int32 values.  (A data page marked PLAIN_DICTIONARY is decoded with the RLE_DICTIONARY codec: that
+    rewrite is the caller's, column.go:850-857, and pqd_chunk_plan_pages makes it.)"""
     NAME, CODE = "PLAIN_DICTIONARY", ENC.PLAIN_DICTIONARY
     DecodeInt32 = Encoding._int32
 

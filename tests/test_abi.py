@@ -36,6 +36,7 @@ def test_abi_version_and_status_names():
     assert L.pqd_abi_version() == 1
     assert L.pqd_status_name(0) == b"OK"
     assert L.pqd_status_name(9) == b"MISSING_VALUES"
+    assert L.pqd_status_name(19) == b"CHECKSUM"
     assert L.pqd_can_decode_in_place(0) == 1 and L.pqd_can_decode_in_place(6) == 1
     assert L.pqd_can_decode_in_place(5) == 0
 

@@ -52,6 +52,67 @@ def test_scan_rejects_corrupt_chunks():
     assert P.chunk.scan_pages(b"", -1) == []
 
 
+def test_scan_bounds_the_nesting_of_skipped_collections():
+    # an unknown field of type LIST whose elements are lists of lists ...: one header byte per level.
+    # The reader gives up past a few dozen levels instead of recursing once per byte.
+    import zlib  # noqa: F401  (the crc test below uses it)
+    for elem in (0x19, 0x1A):  # list of one list / one set
+        bad = bytes([0x15, 0x00]) + bytes([0xF9 if elem == 0x19 else 0xFA]) + bytes([elem]) * 300_000
+        with pytest.raises(P.PqdError) as e:
+            P.chunk.scan_pages(bad, -1)
+        assert e.value.status == P.STATUS.UNEXPECTED_EOF
+    # maps: field of type MAP, one entry, key and value both maps
+    bad = bytes([0x15, 0x00, 0xFB]) + bytes([0x01, 0xBB]) * 150_000
+    with pytest.raises(P.PqdError) as e:
+        P.chunk.scan_pages(bad, -1)
+    assert e.value.status == P.STATUS.UNEXPECTED_EOF
+    # a modest nesting is still skipped: list<list<list<i32>>> with one element each, then STOP
+    ok = bytes([0x15, 0x00, 0x15, 0x00, 0x15, 0x00, 0xF9, 0x19, 0x19, 0x15, 0x02, 0x00])
+    assert len(P.chunk.scan_pages(ok, -1)) == 1
+
+
+def _with_crc(header_fields: bytes, page: bytes, crc: int) -> bytes:
+    """PageHeader{type DATA_PAGE, sizes = len(page), crc, data_page_header{n 1, PLAIN, RLE, RLE}} + page."""
+    def zz(v):
+        v = (v << 1) ^ (v >> 31) if v >= 0 else ((-v) << 1) - 1
+        out = bytearray()
+        while v >= 0x80:
+            out.append((v & 0x7F) | 0x80); v >>= 7
+        out.append(v)
+        return bytes(out)
+    if crc >= 2**31:
+        crc -= 2**32
+    return (bytes([0x15]) + zz(0) + bytes([0x15]) + zz(len(page)) + bytes([0x15]) + zz(len(page)) + bytes([0x15]) + zz(crc) +
+            bytes([0x1C, 0x15]) + zz(1) + bytes([0x15, 0x00, 0x15, 0x06, 0x15, 0x06, 0x00, 0x00]) + page)
+
+
+def test_scan_checks_page_crc32():
+    # FilePages.readPage (file.go:1455-1475): a CRC other than zero must match crc32.ChecksumIEEE of the page bytes
+    import zlib
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 7, 8, 9, 1000, 4099):
+        page = rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+        crc = zlib.crc32(page)
+        good = _with_crc(b"", page, crc)
+        hs = P.chunk.scan_pages(good + good, -1)
+        assert len(hs) == 2 and hs[0].has_crc == 1 and (hs[0].crc & 0xFFFFFFFF) == crc
+        if crc == 0 or n == 0:
+            continue
+        bad = bytearray(good + good)
+        bad[-1] ^= 0x40  # damage the second page
+        with pytest.raises(P.PqdError) as e:
+            P.chunk.scan_pages(bytes(bad), -1)
+        assert e.value.status == P.STATUS.CHECKSUM and e.value.arg == len(good)
+    # a zero CRC is "not set" to the reference: no check
+    assert len(P.chunk.scan_pages(_with_crc(b"", b"abc", 0), -1)) == 1
+    # the reference's own files that carry checksums pass
+    with_crc = 0
+    for rec, arr in K.chunks():
+        hs = P.chunk.scan_pages(arr["chunk"].tobytes(), rec["num_values"])
+        with_crc += sum(1 for h in hs if h.has_crc and h.crc != 0)
+    print("pages with a checksum in the reference files:", with_crc)
+
+
 def test_plan_cuts_pages_as_the_fixture_script_does():
     # the parts of the first pages of every chunk, as make_fixtures.py (following column.go:733-843) sliced them
     manifest, parr = F.load()

@@ -97,7 +97,8 @@ def test_int32_round_trip():
         assert np.array_equal(e.ByteStreamSplit().DecodeInt32(None, O.bss_encode(v.tobytes(), 4)), v)
         if v.size == 0 or v.min() >= 0:
             assert np.array_equal(e.RLEDictionary().DecodeInt32(None, O.rle_dict_encode_int32(v)), v)
-            assert np.array_equal(e.PlainDictionary().DecodeInt32(None, O.rle_dict_encode_int32(v)), v)
+        # plain.DictionaryEncoding.DecodeInt32 is PLAIN (plain/dictionary.go:25-27)
+        assert np.array_equal(e.PlainDictionary().DecodeInt32(None, v.tobytes()), v)
 
 
 def test_int64_int96_float_double_round_trip():

@@ -269,6 +269,50 @@ def test_fused_dictionary(np_dtype, kind_name):
         assert out.data.tobytes() == want.values.tobytes(), label
 
 
+def test_index_pages_without_a_dictionary_are_fixed_up_too():
+    # indexedPageType.Decode + newIndexedPage (dictionary.go:136-162, 217-219; TestNewIndexedPage,
+    # dictionary_test.go:346-352): the int32 indexes of a dictionary-encoded page come back cut to
+    # num_values or zero-extended to it -- the only path a byte-array dictionary column can take
+    P = pkg()
+    rng = np.random.default_rng(61)
+    cases = [("zero-extend", np.array([5, 6, 7], np.int32), 8), ("cut", np.arange(16, dtype=np.int32), 11),
+             ("exact", np.arange(24, dtype=np.int32), 24), ("empty-stream", np.zeros(0, np.int32), 5),
+             ("long-extend", rng.integers(0, 1000, size=3000, dtype=np.int32), 7001),
+             ("long-cut", rng.integers(0, 1000, size=9000, dtype=np.int32), 4097)]
+    specs = [spec(P.ENC.RLE_DICTIONARY, P.KIND.INT32, O.rle_dict_encode_int32(idx), num_values=nv, dst_cap=nv * 4, misalign=k % 16)
+             for k, (_, idx, nv) in enumerate(cases)]
+    outs = decode(specs, grow=False)
+    for (label, idx, nv), out in zip(cases, outs):
+        want = O.indexed_page_fixup(O.rle_dict_decode_int32(O.rle_dict_encode_int32(idx)).values, nv)
+        assert out.status == 0 and out.out_values == nv, label
+        assert np.array_equal(out.data.view(np.int32), want), label
+    # plain RLE int32 values and levels are only ever cut (column.go:940-945)
+    v = np.array([3, 3, 3, 1], np.int32)
+    out = decode([spec(P.ENC.RLE, P.KIND.INT32, O.rle_encode_int32(v, 2), bit_width=2, num_values=9, dst_cap=64)], grow=False)[0]
+    assert out.status == 0 and out.out_values == 4
+
+
+def test_dictionary_length_without_a_pointer_is_rejected():
+    P = pkg()
+    from tests.gpu_util import ctx
+    from parquet_go_amd.runtime import Batch, to_device, DeviceBuffer
+    src = to_device(O.rle_dict_encode_int32(np.arange(8, dtype=np.int32)))
+    dst = DeviceBuffer(64)
+    p = P.Page()
+    p.src, p.src_len, p.dst, p.dst_cap = src.ptr, src.nbytes, dst.ptr, 64
+    p.dict, p.dict_len, p.num_values = None, 10, 8
+    p.encoding, p.kind = P.ENC.RLE_DICTIONARY, P.KIND.INT64
+    b = Batch(ctx(), [p])
+    b.launch(0)
+    res = b.finish(0)
+    assert res[0].status == P.STATUS.INVALID_ARGUMENT
+    # a kind outside pqd_kind is not supported, whatever the encoding
+    p.dict_len, p.kind, p.encoding = 0, 9, P.ENC.PLAIN
+    b = Batch(ctx(), [p])
+    b.launch(0)
+    assert b.finish(0)[0].status == P.STATUS.NOT_SUPPORTED
+
+
 def test_fused_dictionary_strided_and_int96():
     P = pkg()
     rng = np.random.default_rng(8)
