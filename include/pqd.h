@@ -212,6 +212,26 @@ int pqd_optional_expand_device(pqd_ctx* ctx, const uint8_t* def_levels_dev, uint
                                uint32_t width, int32_t offsets_mode, void* dst_dev, uint8_t* validity_dev,
                                void* workspace_dev, uint64_t workspace_bytes, int64_t* info_dev, void* hip_stream);
 
+/*
+ * pqd_optional_expand_device without a workspace argument, for callers that
+ * cannot allocate one: code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc.  It has no counterpart in the reference.
+ * The per-stretch counts live in a static device array of
+ * PQD_NOALLOC_WORKSPACE_BYTES that every GPU the library runs on holds until
+ * the process ends; the call allocates and frees nothing and launches the same
+ * kernels as pqd_optional_expand_device, so the results are identical.
+ * n_slots > PQD_NOALLOC_MAX_SLOTS is refused with PQD_ERR_DST_TOO_SMALL (use the
+ * workspace variant).  All calls on one GPU share that array: two calls whose
+ * kernels may overlap (different streams, different threads) race; serialise
+ * them on one stream or with events.
+ */
+#define PQD_NOALLOC_WORKSPACE_BYTES (1ull << 20)
+#define PQD_NOALLOC_MAX_SLOTS ((PQD_NOALLOC_WORKSPACE_BYTES / 8 - 1) * 2048ull)
+int pqd_optional_expand_noalloc(pqd_ctx* ctx, const uint8_t* def_levels_dev, uint64_t n_slots,
+                                uint8_t max_definition_level, const void* values_dev, uint64_t n_values,
+                                uint32_t width, int32_t offsets_mode, void* dst_dev, uint8_t* validity_dev,
+                                int64_t* info_dev, void* hip_stream);
+
 /* The row search of repeatedPage.Slice (page_repeated.go:73-98) for every row
  * at once: row_starts_dev[k] = index of the k-th repetition level equal to 0,
  * and row_starts_dev[n_rows] = n.  info_dev[0] = n_rows (repeatedPage.NumRows),

@@ -130,6 +130,7 @@ SYMBOLS = {
     "pqd_levels_workspace_size": (_u64, [_u64]),
     "pqd_levels_count_equal_device": (_int, [_vp, _vp, _u64, C.c_uint8, _vp, _u64, _vp, _vp]),
     "pqd_optional_expand_device": (_int, [_vp, _vp, _u64, C.c_uint8, _vp, _u64, C.c_uint32, C.c_int32, _vp, _vp, _vp, _u64, _vp, _vp]),
+    "pqd_optional_expand_noalloc": (_int, [_vp, _vp, _u64, C.c_uint8, _vp, _u64, C.c_uint32, C.c_int32, _vp, _vp, _vp, _vp]),
     "pqd_repeated_row_starts_device": (_int, [_vp, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp]),
     "pqd_chunk_scan_pages": (_int, [_vp, _u64, _i64, C.POINTER(PageHeader), _u64, _pu64, _pi64]),
     "pqd_chunk_plan_pages": (_int, [C.POINTER(PageHeader), _u64, _vp, _u64, _vp, C.POINTER(ColumnInfo), C.POINTER(Page),

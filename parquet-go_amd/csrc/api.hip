@@ -218,6 +218,9 @@ int pqd_ctx_create(int device, pqd_ctx** out) {
     pqd_ctx* ctx = new (std::nothrow) pqd_ctx;
     if (ctx == nullptr) return PQD_ERR_DEVICE;
     ctx->device = device;
+    // with this context's device current: where this GPU keeps the static workspace
+    ctx->levels_scratch = nullptr;
+    if (levels_scratch_address(&ctx->levels_scratch) != PQD_OK) ctx->levels_scratch = nullptr;
     // Side streams for the kernel families of a small batch are an option (PQD_SIDE_BY_SIDE=1): they
     // gain a single-stream caller a few per cent, but every batch of the context goes through the same
     // three, which ties together batches that a caller launched on streams of its own -- and those

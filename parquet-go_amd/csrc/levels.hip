@@ -227,6 +227,14 @@ __global__ __launch_bounds__(LT) void row_starts_kernel(const uint8_t* __restric
 
 uint64_t stretches_of(uint64_t n) { return (n + STRETCH - 1) / STRETCH; }
 
+// The per-stretch counts of pqd_optional_expand_noalloc: a workspace that is part of the code
+// object instead of one the caller brings.  Every GPU the library runs on holds its own copy at
+// its own address for the life of the process; host code only ever uses the address
+// hipGetSymbolAddress reported for the context's device (kept in pqd_ctx), never the array's name.
+constexpr uint64_t SCRATCH_BYTES = PQD_NOALLOC_WORKSPACE_BYTES;
+static __device__ __align__(256) unsigned char scratch[SCRATCH_BYTES];
+static_assert((SCRATCH_BYTES / sizeof(uint64_t) - 1) * STRETCH == PQD_NOALLOC_MAX_SLOTS, "the documented limit is what the array holds");
+
 uint32_t groups_for(uint64_t n_stretches) {
     const uint64_t g = (n_stretches + LT / 64 - 1) / (LT / 64);
     return (uint32_t)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
@@ -243,35 +251,24 @@ bool count_and_scan(const uint8_t* levels, uint64_t n, uint8_t value, void* work
 }
 
 } // namespace
+
+// Called by pqd_ctx_create with the context's device current.
+int levels_scratch_address(void** out) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)) != hipSuccess || p == nullptr) return PQD_ERR_DEVICE;
+    *out = p;
+    return PQD_OK;
+}
+
 } // namespace pqd
 
 using namespace pqd;
 
-extern "C" {
+namespace {
 
-uint64_t pqd_levels_workspace_size(uint64_t n_levels) { return (stretches_of(n_levels) + 1) * sizeof(uint64_t); }
-
-int pqd_levels_count_equal_device(pqd_ctx* ctx, const uint8_t* levels_dev, uint64_t n, uint8_t value, void* workspace_dev,
-                                  uint64_t workspace_bytes, uint64_t* count_dev, void* hip_stream) {
-    if (ctx == nullptr || count_dev == nullptr || (levels_dev == nullptr && n > 0)) return PQD_ERR_INVALID_ARGUMENT;
-    pqd::DeviceGuard guard(ctx->device);
-    if (!guard.ok) return PQD_ERR_DEVICE;
-    if (!count_and_scan(levels_dev, n, value, workspace_dev, workspace_bytes, count_dev, static_cast<hipStream_t>(hip_stream)))
-        return PQD_ERR_INVALID_ARGUMENT;
-    return hipGetLastError() == hipSuccess ? PQD_OK : PQD_ERR_DEVICE;
-}
-
-int pqd_optional_expand_device(pqd_ctx* ctx, const uint8_t* def_levels_dev, uint64_t n_slots, uint8_t max_definition_level,
-                               const void* values_dev, uint64_t n_values, uint32_t width, int32_t offsets_mode, void* dst_dev,
-                               uint8_t* validity_dev, void* workspace_dev, uint64_t workspace_bytes, int64_t* info_dev,
-                               void* hip_stream) {
-    if (ctx == nullptr || info_dev == nullptr || width == 0 || (def_levels_dev == nullptr && n_slots > 0) ||
-        (dst_dev == nullptr && n_slots > 0) || (values_dev == nullptr && n_values > 0))
-        return PQD_ERR_INVALID_ARGUMENT;
-    if (offsets_mode && (width != 4 || values_dev == nullptr || dst_dev == nullptr)) return PQD_ERR_INVALID_ARGUMENT;
-    pqd::DeviceGuard guard(ctx->device);
-    if (!guard.ok) return PQD_ERR_DEVICE;
-    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+int optional_expand(const uint8_t* def_levels_dev, uint64_t n_slots, uint8_t max_definition_level, const void* values_dev,
+                    uint64_t n_values, uint32_t width, int32_t offsets_mode, void* dst_dev, uint8_t* validity_dev,
+                    void* workspace_dev, uint64_t workspace_bytes, int64_t* info_dev, hipStream_t s) {
     if (!count_and_scan(def_levels_dev, n_slots, max_definition_level, workspace_dev, workspace_bytes, nullptr, s))
         return PQD_ERR_INVALID_ARGUMENT;
     const uint64_t ns = stretches_of(n_slots);
@@ -300,6 +297,59 @@ int pqd_optional_expand_device(pqd_ctx* ctx, const uint8_t* def_levels_dev, uint
                            static_cast<const uint8_t*>(values_dev), n_values, width, static_cast<uint8_t*>(dst_dev), validity_dev, starts,
                            ns, info_dev);
     return hipGetLastError() == hipSuccess ? PQD_OK : PQD_ERR_DEVICE;
+}
+
+bool optional_expand_args_ok(pqd_ctx* ctx, const uint8_t* def_levels_dev, uint64_t n_slots, const void* values_dev, uint64_t n_values,
+                             uint32_t width, int32_t offsets_mode, void* dst_dev, int64_t* info_dev) {
+    if (ctx == nullptr || info_dev == nullptr || width == 0 || (def_levels_dev == nullptr && n_slots > 0) ||
+        (dst_dev == nullptr && n_slots > 0) || (values_dev == nullptr && n_values > 0))
+        return false;
+    if (offsets_mode && (width != 4 || values_dev == nullptr || dst_dev == nullptr)) return false;
+    return true;
+}
+
+} // namespace
+
+extern "C" {
+
+uint64_t pqd_levels_workspace_size(uint64_t n_levels) { return (stretches_of(n_levels) + 1) * sizeof(uint64_t); }
+
+int pqd_levels_count_equal_device(pqd_ctx* ctx, const uint8_t* levels_dev, uint64_t n, uint8_t value, void* workspace_dev,
+                                  uint64_t workspace_bytes, uint64_t* count_dev, void* hip_stream) {
+    if (ctx == nullptr || count_dev == nullptr || (levels_dev == nullptr && n > 0)) return PQD_ERR_INVALID_ARGUMENT;
+    pqd::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return PQD_ERR_DEVICE;
+    if (!count_and_scan(levels_dev, n, value, workspace_dev, workspace_bytes, count_dev, static_cast<hipStream_t>(hip_stream)))
+        return PQD_ERR_INVALID_ARGUMENT;
+    return hipGetLastError() == hipSuccess ? PQD_OK : PQD_ERR_DEVICE;
+}
+
+int pqd_optional_expand_device(pqd_ctx* ctx, const uint8_t* def_levels_dev, uint64_t n_slots, uint8_t max_definition_level,
+                               const void* values_dev, uint64_t n_values, uint32_t width, int32_t offsets_mode, void* dst_dev,
+                               uint8_t* validity_dev, void* workspace_dev, uint64_t workspace_bytes, int64_t* info_dev,
+                               void* hip_stream) {
+    if (!optional_expand_args_ok(ctx, def_levels_dev, n_slots, values_dev, n_values, width, offsets_mode, dst_dev, info_dev))
+        return PQD_ERR_INVALID_ARGUMENT;
+    pqd::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return PQD_ERR_DEVICE;
+    return optional_expand(def_levels_dev, n_slots, max_definition_level, values_dev, n_values, width, offsets_mode, dst_dev,
+                           validity_dev, workspace_dev, workspace_bytes, info_dev, static_cast<hipStream_t>(hip_stream));
+}
+
+int pqd_optional_expand_noalloc(pqd_ctx* ctx, const uint8_t* def_levels_dev, uint64_t n_slots, uint8_t max_definition_level,
+                                const void* values_dev, uint64_t n_values, uint32_t width, int32_t offsets_mode, void* dst_dev,
+                                uint8_t* validity_dev, int64_t* info_dev, void* hip_stream) {
+    if (!optional_expand_args_ok(ctx, def_levels_dev, n_slots, values_dev, n_values, width, offsets_mode, dst_dev, info_dev))
+        return PQD_ERR_INVALID_ARGUMENT;
+    // the workspace is the static array: more slots than its counts can cover are refused, not truncated
+    if (n_slots > PQD_NOALLOC_MAX_SLOTS) return PQD_ERR_DST_TOO_SMALL;
+    if (ctx->levels_scratch == nullptr) return PQD_ERR_DEVICE; // hipGetSymbolAddress failed when the context was made
+    pqd::DeviceGuard guard(ctx->device);
+    if (!guard.ok) return PQD_ERR_DEVICE;
+    // The same three kernels as pqd_optional_expand_device.  The counts are written for every
+    // stretch before they are read, so nothing of an earlier call needs clearing.
+    return optional_expand(def_levels_dev, n_slots, max_definition_level, values_dev, n_values, width, offsets_mode, dst_dev,
+                           validity_dev, ctx->levels_scratch, SCRATCH_BYTES, info_dev, static_cast<hipStream_t>(hip_stream));
 }
 
 int pqd_repeated_row_starts_device(pqd_ctx* ctx, const uint8_t* rep_levels_dev, uint64_t n, uint64_t* row_starts_dev, uint64_t row_cap,

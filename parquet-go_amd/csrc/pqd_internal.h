@@ -10,6 +10,7 @@
 struct pqd_ctx {
     int device;
     hipStream_t side[3]; // small batches run their kernel families side by side on these (null: not created)
+    void* levels_scratch; // this device's copy of the static workspace of pqd_optional_expand_noalloc (null: look-up failed)
 };
 
 struct pqd_dict {
@@ -221,6 +222,8 @@ void launch_dlba(const DevPage* pages, DevResult* results, const uint32_t* items
 void launch_dba(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_values,
                 hipStream_t stream);
 void launch_sum_lengths(const int32_t* v, uint64_t n, uint32_t* out, hipStream_t stream);
+
+int levels_scratch_address(void** out); // device address of the static workspace, for the current device
 
 constexpr uint32_t RLE_TILE = 2048; // output values per expand workgroup
 
