@@ -40,20 +40,25 @@ struct pqd_batch {
     size_t arena_bytes = 0;
     DevPage* d_items = nullptr;
     DevResult* d_results = nullptr;
-    FamilyList fam[16];
+    FamilyList fam[N_FAMILIES];
     // RLE expand grids, one per RLE hybrid family
-    uint64_t* d_rle_tile_prefix[4] = {nullptr, nullptr, nullptr, nullptr};
-    uint32_t* d_rle_tile_item[4] = {nullptr, nullptr, nullptr, nullptr}; // grid tile -> position in the family list (null: the kernel searches the prefix)
-    uint64_t rle_tiles[4] = {0, 0, 0, 0};
+    uint64_t* d_rle_tile_prefix[6] = {};
+    uint32_t* d_rle_tile_item[6] = {}; // grid tile -> position in the family list (null: the kernel searches the prefix)
+    uint64_t rle_tiles[6] = {};
+    uint64_t lds_dict_bytes[6] = {}; // LDS families: the largest dictionary of the family, in bytes
+    uint32_t launches = 0;           // times the batch has been launched
+    LdsPlan lds_plan[6];             // ... their launch shape
+    uint32_t* d_lds_wg_item[6] = {}; // ... the item each workgroup starts in
+    uint32_t* d_lds_seg_last[6] = {}; // ... per item, the last one from there on with the same dictionary
     uint64_t rle_steps = 0;
     RleChunks ck; // long RLE pages indexed chunk by chunk
     // a small batch forks its independent kernel families onto the context's side streams
     bool side_by_side = false;
     hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
     // generic tile grids for the element-parallel families
-    uint64_t max_src[16] = {0}; // longest src of each family, sizes the tile grids
+    uint64_t max_src[N_FAMILIES] = {0}; // longest src of each family, sizes the tile grids
     uint64_t dba_max_values = 0; // most values a DELTA_BYTE_ARRAY page of the batch is expected to hold
-    uint64_t flat_blocks[16] = {0}; // DELTA families decoded tile by tile: most blocks a page may hold (0: not used)
+    uint64_t flat_blocks[N_FAMILIES] = {0}; // DELTA families decoded tile by tile: most blocks a page may hold (0: not used)
     std::vector<DevResult> h_results;
     ~pqd_batch() {
         if (arena) (void)hipFree(arena);
@@ -94,12 +99,19 @@ int32_t elem_width_of(int32_t kind, int32_t bit_width) {
 // encoding.NotSupported would answer (encoding/notsupported.go:163-197).
 // The RLE hybrid families share the index kernel; each has an expand kernel and a tile grid of its own.
 constexpr size_t SIDE_BY_SIDE_MAX_ITEMS = 1024;     // batches up to this size fork their families onto side streams
-constexpr int RLE_GRIDS = 4;
+constexpr int RLE_GRIDS = 6;
+static_assert(RLE_GRIDS == sizeof(pqd_batch::rle_tiles) / sizeof(uint64_t), "one tile grid per RLE hybrid family");
 constexpr size_t RLE_CHUNKED_MAX_PAGES = 512;      // batches with more RLE pages than this index them one wavefront each
 constexpr uint64_t RLE_CHUNKED_MIN_BYTES = 16384;   // shorter pages are not worth cutting up ...
 constexpr uint64_t RLE_CHUNKED_MIN_BYTES_FEW = 4096; // ... unless the batch holds so few that wavefronts would idle
 constexpr size_t RLE_CHUNKED_FEW_PAGES = 128;
-constexpr int32_t RLE_FAMILY[RLE_GRIDS] = {FAM_RLE, FAM_RLE_BYTES, FAM_RLE_DICT8, FAM_RLE_DICT4};
+constexpr int32_t RLE_FAMILY[RLE_GRIDS] = {FAM_RLE, FAM_RLE_BYTES, FAM_RLE_DICT8, FAM_RLE_DICT4, FAM_RLE_LDS8, FAM_RLE_LDS4};
+inline bool is_lds_family(int32_t family) { return family == FAM_RLE_LDS8 || family == FAM_RLE_LDS4; }
+// An LDS-resident dictionary pays when the family decodes at least this many tiles of 2048 values (below that the
+// copies of the dictionary, one per workgroup, outweigh what the gathers save) ...
+constexpr uint64_t LDS_DICT_MIN_TILES = 256;
+// ... and the dictionary is not much larger than what a workgroup can hold
+constexpr uint64_t LDS_DICT_DEFAULT_MAX_BYTES = 1ull << 20;
 inline int rle_grid(int32_t family) {
     for (int g = 0; g < RLE_GRIDS; g++) if (RLE_FAMILY[g] == family) return g;
     return -1;
@@ -218,6 +230,18 @@ int pqd_ctx_create(int device, pqd_ctx** out) {
     pqd_ctx* ctx = new (std::nothrow) pqd_ctx;
     if (ctx == nullptr) return PQD_ERR_DEVICE;
     ctx->device = device;
+    hipDeviceProp_t prop;
+    ctx->n_cus = hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0 ? (uint32_t)prop.multiProcessorCount : 256;
+    // PQD_DICT_LDS: 0 = dictionary pages never go through an LDS-resident dictionary, 2 = whenever the page
+    // qualifies, otherwise when it is expected to pay.  PQD_DICT_LDS_MAX_BYTES / PQD_DICT_LDS_CAP_BYTES: the
+    // largest dictionary that takes the path, and how much of a dictionary LDS may hold (both for experiments and tests).
+    const char* lds_opt = getenv("PQD_DICT_LDS");
+    ctx->dict_lds = lds_opt != nullptr && lds_opt[0] >= '0' && lds_opt[0] <= '2' ? lds_opt[0] - '0' : 1;
+    if (ctx->dict_lds != 0 && !rle_dict_lds_init()) ctx->dict_lds = 0;
+    const char* lds_max = getenv("PQD_DICT_LDS_MAX_BYTES");
+    ctx->dict_lds_max_bytes = lds_max != nullptr ? strtoull(lds_max, nullptr, 10) : LDS_DICT_DEFAULT_MAX_BYTES;
+    const char* lds_cap = getenv("PQD_DICT_LDS_CAP_BYTES");
+    ctx->dict_lds_cap_bytes = lds_cap != nullptr ? strtoull(lds_cap, nullptr, 10) : 0;
     // with this context's device current: where this GPU keeps the static workspace
     ctx->levels_scratch = nullptr;
     if (levels_scratch_address(&ctx->levels_scratch) != PQD_OK) ctx->levels_scratch = nullptr;
@@ -339,6 +363,32 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
         b->map[i] = m;
     }
 
+    // ---- dictionary pages with dense 4- or 8-byte values: through an LDS-resident dictionary when that pays ----
+    auto rle_steps_of = [](const DevPage& d) {
+        const uint64_t stride = d.dst_stride > 0 ? (uint64_t)d.dst_stride : (uint64_t)d.elem_width;
+        uint64_t bound = stride ? d.dst_cap / stride + 1 : 0;
+        if (d.num_values >= 0 && (uint64_t)d.num_values < bound) bound = (uint64_t)d.num_values;
+        return std::max<uint64_t>(1, (bound + RLE_TILE - 1) / RLE_TILE);
+    };
+    if (ctx->dict_lds != 0) {
+        for (int32_t from : {FAM_RLE_DICT8, FAM_RLE_DICT4}) {
+            const int32_t to = from == FAM_RLE_DICT8 ? FAM_RLE_LDS8 : FAM_RLE_LDS4;
+            auto candidate = [&](const DevPage& d) {
+                return d.family == from && d.fused && (d.dst_stride == 0 || d.dst_stride == d.elem_width) &&
+                       d.dict_len * (uint64_t)d.elem_width <= ctx->dict_lds_max_bytes;
+            };
+            uint64_t tiles = 0;
+            for (const DevPage& d : b->items)
+                if (candidate(d)) tiles += rle_steps_of(d);
+            if (tiles == 0 || (ctx->dict_lds == 1 && tiles < LDS_DICT_MIN_TILES)) continue;
+            for (DevPage& d : b->items)
+                if (candidate(d)) {
+                    d.family = to;
+                    b->lds_dict_bytes[rle_grid(to)] = std::max<uint64_t>(b->lds_dict_bytes[rle_grid(to)], d.dict_len * (uint64_t)d.elem_width);
+                }
+        }
+    }
+
     // ---- family lists and the RLE tile grids ----
     std::vector<uint64_t> rle_prefix[RLE_GRIDS];
     for (uint32_t k = 0; k < b->items.size(); k++) {
@@ -347,10 +397,7 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
         b->max_src[d.family] = std::max<uint64_t>(b->max_src[d.family], d.src_len);
         if (is_rle(d.family)) {
             const int g = rle_grid(d.family);
-            const uint64_t stride = d.dst_stride > 0 ? (uint64_t)d.dst_stride : (uint64_t)d.elem_width;
-            uint64_t bound = stride ? d.dst_cap / stride + 1 : 0;
-            if (d.num_values >= 0 && (uint64_t)d.num_values < bound) bound = (uint64_t)d.num_values;
-            const uint64_t steps = std::max<uint64_t>(1, (bound + RLE_TILE - 1) / RLE_TILE);
+            const uint64_t steps = rle_steps_of(d);
             if (steps > 0x7fffffffull) { delete b; return PQD_ERR_INVALID_ARGUMENT; }
             d.group = d.family == FAM_RLE_BYTES ? 8 : 1; // 1-byte elements: 2 KB per step is too little work for a workgroup
             d.n_steps = (uint32_t)steps;
@@ -433,14 +480,39 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_items = carve(n_items * sizeof(DevPage));
     const size_t o_results = carve(n_items * sizeof(DevResult));
-    size_t o_fam[16];
-    for (int f = 0; f < 16; f++) o_fam[f] = carve(b->fam[f].items.size() * sizeof(uint32_t));
+    size_t o_fam[N_FAMILIES];
+    for (int f = 0; f < N_FAMILIES; f++) o_fam[f] = carve(b->fam[f].items.size() * sizeof(uint32_t));
     size_t o_rle_prefix[RLE_GRIDS], o_rle_tile_item[RLE_GRIDS];
     bool with_tile_item[RLE_GRIDS];
     for (int g = 0; g < RLE_GRIDS; g++) {
         o_rle_prefix[g] = carve(rle_prefix[g].size() * sizeof(uint64_t));
-        with_tile_item[g] = b->rle_tiles[g] <= (1ull << 24);
+        with_tile_item[g] = b->rle_tiles[g] <= (1ull << 24) && !is_lds_family(RLE_FAMILY[g]); // the persistent kernel walks the prefix
         o_rle_tile_item[g] = carve(with_tile_item[g] ? b->rle_tiles[g] * sizeof(uint32_t) : 0);
+    }
+    size_t o_lds_wg[RLE_GRIDS] = {}, o_lds_seg[RLE_GRIDS] = {};
+    std::vector<uint32_t> lds_wg[RLE_GRIDS], lds_seg[RLE_GRIDS];
+    for (int g = 0; g < RLE_GRIDS; g++) {
+        if (!is_lds_family(RLE_FAMILY[g]) || b->rle_tiles[g] == 0) continue;
+        const std::vector<uint32_t>& list = b->fam[RLE_FAMILY[g]].items;
+        const LdsPlan plan = rle_dict_lds_plan(b->rle_tiles[g], b->lds_dict_bytes[g], ctx->dict_lds_cap_bytes, ctx->n_cus);
+        b->lds_plan[g] = plan;
+        lds_wg[g].resize(2 * (size_t)plan.grid);
+        for (uint32_t w = 0, k = 0; w < plan.grid; w++) {
+            const uint64_t t0 = b->rle_tiles[g] * w / plan.grid, t1 = b->rle_tiles[g] * (w + 1) / plan.grid;
+            while (k + 1 < list.size() && rle_prefix[g][k + 1] <= t0) k++;
+            lds_wg[g][2 * w] = k;
+            uint32_t k1 = k;
+            while (t1 > 0 && k1 + 1 < list.size() && rle_prefix[g][k1 + 1] <= t1 - 1) k1++;
+            lds_wg[g][2 * w + 1] = k1;
+        }
+        lds_seg[g].resize(list.size());
+        for (size_t k = list.size(); k-- > 0;) {
+            const DevPage& d = b->items[list[k]];
+            const bool same = k + 1 < list.size() && b->items[list[k + 1]].dict == d.dict && b->items[list[k + 1]].dict_len == d.dict_len;
+            lds_seg[g][k] = same ? lds_seg[g][k + 1] : (uint32_t)k;
+        }
+        o_lds_wg[g] = carve(lds_wg[g].size() * sizeof(uint32_t));
+        o_lds_seg[g] = carve(lds_seg[g].size() * sizeof(uint32_t));
     }
     const size_t o_rle_tile_run = carve(b->rle_steps * sizeof(uint32_t));
     const size_t nck = b->ck.n_chunks, npk = ck_items.size();
@@ -531,7 +603,7 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
     bool ok = true;
     if (n_items) ok = ok && hip_ok(hipMemcpy(b->d_items, b->items.data(), n_items * sizeof(DevPage), hipMemcpyHostToDevice));
     ok = ok && hip_ok(hipMemset(b->d_results, 0, std::max<size_t>(1, n_items) * sizeof(DevResult)));
-    for (int f = 0; f < 16; f++) {
+    for (int f = 0; f < N_FAMILIES; f++) {
         b->fam[f].dev = reinterpret_cast<uint32_t*>(a + o_fam[f]);
         if (!b->fam[f].items.empty())
             ok = ok && hip_ok(hipMemcpy(b->fam[f].dev, b->fam[f].items.data(), b->fam[f].items.size() * sizeof(uint32_t),
@@ -547,6 +619,13 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
             ok = ok && hip_ok(hipMemcpy(b->d_rle_tile_item[g], tile_item.data(), tile_item.size() * sizeof(uint32_t),
                                         hipMemcpyHostToDevice));
         }
+    }
+    for (int g = 0; g < RLE_GRIDS; g++) {
+        if (lds_wg[g].empty()) continue;
+        b->d_lds_wg_item[g] = reinterpret_cast<uint32_t*>(a + o_lds_wg[g]);
+        b->d_lds_seg_last[g] = reinterpret_cast<uint32_t*>(a + o_lds_seg[g]);
+        ok = ok && hip_ok(hipMemcpy(b->d_lds_wg_item[g], lds_wg[g].data(), lds_wg[g].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        ok = ok && hip_ok(hipMemcpy(b->d_lds_seg_last[g], lds_seg[g].data(), lds_seg[g].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     }
     if (nck > 0) {
         ok = ok && hip_ok(hipMemcpy(a + o_ck_items, ck_items.data(), npk * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -580,14 +659,21 @@ int pqd_batch_launch(pqd_batch* b, void* hip_stream) {
                  b->flat_blocks[FAM_DELTA32_CHAINED], s);
     launch_delta(b->d_items, b->d_results, b->fam[FAM_DELTA64].dev, (uint32_t)b->fam[FAM_DELTA64].items.size(), true, b->flat_blocks[FAM_DELTA64], s);
     launch_rle_chunked(b->d_items, b->d_results, b->ck, s_rle);
+    b->launches++;
     for (int g = 0; g < RLE_GRIDS; g++) {
+        if (is_lds_family(RLE_FAMILY[g])) continue; // these index their pages in the launch that decodes them
         const FamilyList& f = b->fam[RLE_FAMILY[g]];
         launch_rle_index(b->d_items, b->d_results, f.dev, (uint32_t)f.items.size(), b->ck.pk_flag, s_rle);
     }
     for (int g = 0; g < RLE_GRIDS; g++) {
         const FamilyList& f = b->fam[RLE_FAMILY[g]];
-        launch_rle_expand(b->d_items, b->d_results, f.dev, (uint32_t)f.items.size(), b->d_rle_tile_prefix[g], b->d_rle_tile_item[g],
-                          b->rle_tiles[g], RLE_FAMILY[g], s_rle);
+        if (is_lds_family(RLE_FAMILY[g]))
+            launch_rle_dict_lds(b->d_items, b->d_results, f.dev, (uint32_t)f.items.size(), b->d_rle_tile_prefix[g], b->rle_tiles[g],
+                                RLE_FAMILY[g] == FAM_RLE_LDS8 ? 8 : 4, b->lds_plan[g], b->d_lds_wg_item[g], b->d_lds_seg_last[g], b->ck.pk_flag,
+                                b->launches, s_rle);
+        else
+            launch_rle_expand(b->d_items, b->d_results, f.dev, (uint32_t)f.items.size(), b->d_rle_tile_prefix[g], b->d_rle_tile_item[g],
+                              b->rle_tiles[g], RLE_FAMILY[g], s_rle);
     }
     auto fam_n = [&](int f) { return (uint32_t)b->fam[f].items.size(); };
     launch_bitpacked(b->d_items, b->d_results, b->fam[FAM_BITPACKED].dev, fam_n(FAM_BITPACKED), b->max_src[FAM_BITPACKED] * 8, s_flat);
@@ -630,7 +716,16 @@ int pqd_batch_finish(pqd_batch* b, void* hip_stream, pqd_page* pages, uint64_t n
         p.out_values = r.out_values;
         p.out_bytes = r.out_bytes;
         p.consumed = r.consumed;
-        if (is_rle(d.family) && d.fused && r.status == PQD_OK && r.aux != ~0ull) {
+        if (is_lds_family(d.family)) {
+            // index and decode ran in one launch and wrote apart: capacity first, then the first bad index of THIS launch
+            if (r.status == PQD_OK && r.need_bytes > 0) {
+                p.status = PQD_ERR_DST_TOO_SMALL;
+                p.status_arg = (int64_t)r.need_bytes;
+            } else if (r.status == PQD_OK && r.bad != 0 && (uint32_t)(r.bad >> 32) == b->launches) {
+                p.status = PQD_ERR_INDEX_OUT_OF_BOUNDS;
+                p.status_arg = (int64_t)(0xffffffffull - (r.bad & 0xffffffffull));
+            }
+        } else if (is_rle(d.family) && d.fused && r.status == PQD_OK && r.aux != ~0ull) {
             p.status = PQD_ERR_INDEX_OUT_OF_BOUNDS; // the reference panics here (errors.go:75-83)
             p.status_arg = (int64_t)r.aux;
         }

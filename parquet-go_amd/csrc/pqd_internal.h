@@ -10,6 +10,10 @@
 struct pqd_ctx {
     int device;
     hipStream_t side[3]; // small batches run their kernel families side by side on these (null: not created)
+    uint32_t n_cus;       // compute units of the device
+    int32_t dict_lds;     // dictionary pages through an LDS-resident dictionary: 0 never, 1 when it pays, 2 whenever possible
+    uint64_t dict_lds_max_bytes; // dictionaries above this size never take that path
+    uint64_t dict_lds_cap_bytes; // at most this much of a dictionary is kept in LDS (0: all that fits)
     void* levels_scratch; // this device's copy of the static workspace of pqd_optional_expand_noalloc (null: look-up failed)
 };
 
@@ -99,6 +103,11 @@ struct DevResult {
     uint64_t n_runs;   // RLE: runs in the table
     uint64_t total;    // RLE: values the stream holds; DELTA: header total
     uint64_t aux;      // family specific
+    uint32_t first[4]; // RLE: the first entry of the run table (a Run), zero when the table is empty
+    // dictionary pages through an LDS-resident dictionary (their index and their decode run in one launch and
+    // write disjoint fields):
+    uint64_t need_bytes; // destination bytes the page asks for when dst_cap is too small, else 0
+    unsigned long long bad; // launch number << 32 | ~(first position whose index lies outside the dictionary)
 };
 
 enum Family : int32_t {
@@ -116,7 +125,10 @@ enum Family : int32_t {
     FAM_ERROR = 11,     // rejected on the host; status already set
     FAM_DELTA32_CHAINED = 12, // a length stream that starts where another item's stream ended
     FAM_RLE_DICT8 = 13, // RLE hybrid through a dictionary of 8-byte values
-    FAM_RLE_DICT4 = 14  // ... of 4-byte values
+    FAM_RLE_DICT4 = 14, // ... of 4-byte values
+    FAM_RLE_LDS8 = 15,  // RLE hybrid through a dictionary of 8-byte values held in LDS, dense destination
+    FAM_RLE_LDS4 = 16,  // ... of 4-byte values
+    N_FAMILIES = 20
 };
 
 // Pointers read out of a descriptor are generic to the compiler, which then
@@ -208,6 +220,23 @@ uint32_t rle_chunk_bytes();
 void launch_rle_chunked(const DevPage* pages, DevResult* results, const RleChunks& c, hipStream_t stream);
 void launch_rle_expand(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
                        const uint64_t* tile_prefix, const uint32_t* tile_item, uint64_t n_tiles, int32_t family, hipStream_t stream);
+
+// Dictionary pages through an LDS-resident dictionary (persistent workgroups).
+bool rle_dict_lds_init();            // false: the kernels cannot get their LDS; the path is not used
+uint32_t rle_dict_lds_capacity();    // bytes of dictionary a workgroup can hold
+struct LdsPlan {                     // launch shape of a family, fixed when the batch is made
+    uint32_t grid = 0;               // persistent workgroups
+    uint32_t lds_bytes = 0, dict_bytes = 0, tab_cap = 0;
+    bool part = false;               // some dictionary of the family is larger than what LDS holds of it
+};
+LdsPlan rle_dict_lds_plan(uint64_t n_tiles, uint64_t max_dict_bytes, uint64_t cap_bytes, uint32_t n_cus);
+// wg_item[2b], wg_item[2b + 1]: positions in the family list of the items that hold workgroup b's first and last
+// tile (tiles n_tiles * b / grid and n_tiles * (b + 1) / grid - 1); seg_last[i]: the last position from i on whose
+// item shares item i's dictionary; pk_flag: the chunked index's per-page flags; launch: how many times the batch
+// has been launched, this launch included
+void launch_rle_dict_lds(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
+                         const uint64_t* tile_prefix, uint64_t n_tiles, int32_t elem, const LdsPlan& plan, const uint32_t* wg_item,
+                         const uint32_t* seg_last, const uint32_t* pk_flag, uint32_t launch, hipStream_t stream);
 
 void launch_bitpacked(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_values,
                       hipStream_t stream);

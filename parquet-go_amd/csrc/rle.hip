@@ -20,6 +20,8 @@
 //               mixed tiles look their runs up in an LDS copy of the table.
 //               With a dictionary the index goes straight to the gather and is
 //               never written to memory.
+#include <algorithm>
+
 #include "pqd_internal.h"
 
 namespace pqd {
@@ -33,10 +35,13 @@ __device__ inline Run load_run(gptr<const Run> runs, uint64_t i) {
     return r;
 }
 
-__device__ inline void store_run(gptr<Run> runs, uint64_t i, const Run& r) {
+// The first entry is also kept in the page's result, where the expand kernels find it without
+// another dependent look-up.
+__device__ inline void store_run(gptr<Run> runs, uint64_t i, const Run& r, DevResult* res) {
     u32x4 w;
     w.x = r.out_start; w.y = r.in_off; w.z = r.value; w.w = r.count_kind;
     *(gptr<u32x4>)(runs + i) = w;
+    if (i == 0) *(gptr<u32x4>)(as_global(res)->first) = w;
 }
 
 // ------------------------------------------------------------------ index --
@@ -222,15 +227,15 @@ __device__ inline PageSetup page_setup(const DevPage& pg) {
     return ps;
 }
 
-__global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
-                                                      const uint32_t* __restrict__ items, const uint32_t* pk_flag) {
-    __shared__ uint32_t ring[IRING_BYTES / 4];
-    __shared__ ICtl ctl;
-    const uint32_t item = items[blockIdx.x];
-    const DevPage& pg = pages[item];
-    if (pg.ck_index >= 0 && pk_flag[pg.ck_index] == 0) return; // indexed by the chunked kernels
-    DevResult* res = &results[item];
-    const uint32_t tid = threadIdx.x;
+// Hand-off through LDS inside ONE wavefront: its LDS operations execute in order, so it is enough
+// that the compiler keeps them in order and the earlier ones have landed.
+__device__ inline void isync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// The run table of one page, built by one wavefront (`tid` = its lane) with a ring and a control
+// block of its own in LDS.  EXPAND_FIELDS: also reset the result fields the expand kernels fill
+// in (not when the same launch's expand code may already be at work on the page).
+template <bool EXPAND_FIELDS>
+__device__ inline void rle_index_page(uint32_t* ring, ICtl& ctl, const DevPage& pg, DevResult* res, const uint32_t tid) {
     gptr<const uint8_t> src = as_global(pg.src);
     const PageSetup ps = page_setup(pg);
     const uint64_t src_len = ps.src_len, start = ps.start;
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict
         ctl.arg = arg0;
         ctl.done = (mis + start >= end) ? 1 : 0;
     }
-    __syncthreads();
+    isync();
 
     uint64_t c_next = 0;
     gptr<Run> runs = as_global(pg.runs);
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict
             *reinterpret_cast<u32x4*>(&ring[(v & IRING_MASK) >> 2]) = w;
             c_next++;
         }
-        __syncthreads();
+        isync();
         {
             // Every lane parses the run header that WOULD start at its byte of a 64-byte
             // window; the headers that really follow one another from `pos` are then picked
@@ -315,7 +320,7 @@ __global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict
                     r.in_off = h.in_off;
                     r.value = h.value;
                     r.count_kind = ((uint32_t)h.nvals << 1) | (h.kind == 1 ? 1u : 0u);
-                    store_run(runs, n_runs + __popcll(recm & ((1ull << tid) - 1)), r);
+                    store_run(runs, n_runs + __popcll(recm & ((1ull << tid) - 1)), r, res);
                 }
                 publish_steps(tile_run, n_steps, keep && h.kind != 2, total + x - h.nvals, h.nvals,
                               (uint32_t)(n_runs + __popcll(recm & ((1ull << tid) - 1))), tid);
@@ -341,7 +346,7 @@ __global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict
                             r.in_off = g.in_off;
                             r.value = g.value;
                             r.count_kind = ((uint32_t)g.nvals << 1) | (g.kind == 1 ? 1u : 0u);
-                            store_run(runs, n_runs, r);
+                            store_run(runs, n_runs, r, res);
                         }
                         publish_steps(tile_run, n_steps, tid == 0, total, g.nvals, (uint32_t)n_runs, tid);
                         n_runs++;
@@ -358,7 +363,7 @@ __global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict
                 else if (pos >= end) ctl.done = 1;
             }
         }
-        __syncthreads();
+        isync();
     }
     if (tid == 0) {
         res->status = ctl.status;
@@ -367,10 +372,22 @@ __global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict
         res->n_runs = ctl.n_runs;
         res->total = ctl.total;
         res->consumed = ctl.pos >= mis ? ctl.pos - mis : 0;
-        res->out_values = 0;
-        res->out_bytes = 0;
-        res->aux = ~0ull; // position of the first out-of-range dictionary index
+        if (EXPAND_FIELDS) {
+            res->out_values = 0;
+            res->out_bytes = 0;
+            res->aux = ~0ull; // position of the first out-of-range dictionary index
+        }
     }
+}
+
+__global__ __launch_bounds__(IT) void rle_index_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                      const uint32_t* __restrict__ items, const uint32_t* pk_flag) {
+    __shared__ uint32_t ring[IRING_BYTES / 4];
+    __shared__ ICtl ctl;
+    const uint32_t item = items[blockIdx.x];
+    const DevPage& pg = pages[item];
+    if (pg.ck_index >= 0 && pk_flag[pg.ck_index] == 0) return; // indexed by the chunked kernels
+    rle_index_page<true>(ring, ctl, pg, &results[item], threadIdx.x);
 }
 
 
@@ -699,7 +716,7 @@ __global__ __launch_bounds__(CKT) void rle_chunk_emit_kernel(const DevPage* __re
             r.in_off = h.in_off;
             r.value = h.value;
             r.count_kind = ((uint32_t)h.nvals << 1) | (h.kind == 1 ? 1u : 0u);
-            store_run(runs, r_at, r);
+            store_run(runs, r_at, r, &results[item]);
         }
         publish_steps(tile_run, n_steps, rec, v_at, h.nvals, (uint32_t)r_at, lane);
     }
@@ -1208,7 +1225,679 @@ __global__ __launch_bounds__(ET) __attribute__((amdgpu_waves_per_eu(FAMILY == FA
     }
 }
 
+
+// ------------------------------------------------- dictionary held in LDS --
+//
+// Dictionary pages through a dictionary that is kept in LDS (rle.DictionaryEncoding.DecodeInt32 +
+// newIndexedPage + Dictionary.Lookup in one pass: encoding/rle/dictionary.go:30-37,
+// dictionary.go:136-162, dictionaryLookup32/64 dictionary_amd64.s:578-711).  A gather from
+// memory pulls a whole cache line over the CU's L1-L2 port for every index; a gather from LDS
+// costs an LDS read.  So, for dense 4- and 8-byte values: a persistent workgroup of sixteen
+// wavefronts per CU copies the dictionary (or as much of it as fits; indexes past that part
+// still go to memory) into LDS once and then decodes a contiguous stretch of the family's
+// tiles.  Inside the workgroup the wavefronts are independent: each takes whole tiles, reads
+// the packed indexes of its values straight from memory (G consecutive values per lane, so a
+// store instruction of the wavefront covers contiguous memory; the 8-byte loads of neighbouring
+// lanes overlap inside a few cache lines and the now undisturbed L1 serves them), looks the
+// values up in LDS and stores them.  There is no workgroup barrier except around a change of
+// dictionary.  A tile that is not inside one run copies the run-table entries that meet it to
+// a table of the wavefront's own in LDS and every lane bisects there.
+
+constexpr int LDT = 1024;                 // threads of a persistent workgroup
+constexpr uint32_t LD_WAVES = LDT / 64;
+constexpr uint32_t LD_INDEX_BYTES = IRING_BYTES + 64; // LDS of a wavefront while it indexes a page: ring + control block
+static_assert(sizeof(ICtl) <= 64, "the control block of the index fits its slot");
+typedef uint64_t u64_a1 __attribute__((aligned(1)));
+typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+
+__device__ inline void ld_wave_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ inline uint32_t ld_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ inline uint64_t ld_uniform(uint64_t v) { return ((uint64_t)ld_uniform((uint32_t)(v >> 32)) << 32) | ld_uniform((uint32_t)v); }
+
+// 64 bits of the stream starting at bit `bit` of src (little-endian).  `lim` is the end of the
+// last aligned 16-byte chunk that holds a byte of the page: whole 8-byte loads stay below it,
+// the last bytes are assembled one at a time.
+__device__ inline uint64_t read_bits(gptr<const uint8_t> src, const uint8_t* lim, uint64_t bit) {
+    gptr<const uint8_t> q = src + (bit >> 3);
+    const uint32_t s = (uint32_t)bit & 7;
+    uint64_t w = 0;
+    if ((const uint8_t*)q + 8 <= lim) {
+        w = *(gptr<const u64_a1>)q;
+    } else {
+        for (uint32_t b = 0; b < 8; b++)
+            if ((const uint8_t*)q + b < lim) w |= (uint64_t)q[b] << (8 * b);
+    }
+    return w >> s;
+}
+
+// G consecutive fields of `bw` bits from bit `bit` on.
+template <int G>
+__device__ inline void read_fields(gptr<const uint8_t> src, const uint8_t* lim, uint64_t bit, uint32_t bw, uint32_t mask,
+                                   uint32_t (&v)[G]) {
+    if (G * bw + 7 <= 64) {
+        const uint64_t w = read_bits(src, lim, bit);
+#pragma unroll
+        for (int g = 0; g < G; g++) v[g] = (uint32_t)(w >> (g * bw)) & mask;
+    } else if (G > 2 && 2 * bw + 7 <= 64) {
+#pragma unroll
+        for (int g = 0; g < G; g += 2) {
+            const uint64_t w = read_bits(src, lim, bit + (uint64_t)g * bw);
+            v[g] = (uint32_t)w & mask;
+            v[(g + 1) % G] = (uint32_t)(w >> bw) & mask;
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; g++) v[g] = (uint32_t)read_bits(src, lim, bit + (uint64_t)g * bw) & mask;
+    }
+}
+
+template <int ELEM> struct LdElem;
+template <> struct LdElem<8> { typedef uint64_t T; };
+template <> struct LdElem<4> { typedef uint32_t T; };
+
+// What a wavefront knows about the item its current tile belongs to.
+struct LdItem {
+    const DevPage* pg;
+    DevResult* res;
+    uint64_t total, n_runs, n_out;
+    uint64_t tile_lo, tile_hi;     // the item's tiles in the family's grid
+    uint32_t bw;
+    Run only;                      // the first run of the page (pages that are one run have no other)
+};
+
+template <int ELEM>
+struct LdDict {
+    const typename LdElem<ELEM>::T* lds;  // the first lds_n entries
+    gptr<const typename LdElem<ELEM>::T> mem;
+    uint32_t lds_n;
+    uint32_t launch;               // number of this launch of the batch (tags the out-of-range positions)
+    uint64_t len;
+};
+
+// The first position of a page whose index lies outside the dictionary is kept as a maximum of
+// (launch << 32 | ~position): a later launch of the batch outranks what an earlier one left, so
+// nothing has to be cleared in between, and inside a launch the least position wins.
+__device__ inline void ld_record_bad(DevResult* res, uint32_t launch, uint64_t pos) {
+    atomicMax(reinterpret_cast<unsigned long long*>(&res->bad), ((unsigned long long)launch << 32) | (0xffffffffull - (pos & 0xffffffffull)));
+}
+
+// dict[idx] for G indexes at page positions pos.. (zero and a recorded position for an index outside the dictionary)
+template <int ELEM, int G>
+__device__ inline void ld_lookup(const LdDict<ELEM>& d, DevResult* res, uint64_t pos, const uint32_t (&v)[G],
+                                 typename LdElem<ELEM>::T (&x)[G]) {
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const uint32_t idx = v[g];
+        if (idx < d.lds_n) x[g] = d.lds[idx];
+        else if ((uint64_t)idx < d.len) x[g] = d.mem[idx];
+        else {
+            x[g] = 0;
+            ld_record_bad(res, d.launch, pos + g);
+        }
+    }
+}
+
+// Stores the values of page positions [pos, pos + G) that lie below `end`.
+template <int ELEM, int G>
+__device__ inline void ld_store(const DevPage& pg, uint64_t pos, uint64_t end, const typename LdElem<ELEM>::T (&x)[G]) {
+    gptr<uint8_t> p = as_global(pg.dst) + pos * ELEM;
+    if (G * ELEM == 16 && pos + G <= end) { // a full step: one 16-byte store
+        if (ELEM == 8) {
+            u64x2_a8 w;
+            w.x = x[0]; w.y = x[1 % G];
+            *(gptr<u64x2_a8>)p = w;
+        } else {
+            u32x4_a4 w;
+            w.x = (uint32_t)x[0]; w.y = (uint32_t)x[1 % G]; w.z = (uint32_t)x[2 % G]; w.w = (uint32_t)x[3 % G];
+            *(gptr<u32x4_a4>)p = w;
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            if (pos + g >= end) break;
+            if (ELEM == 8) {
+                u32x2_a4 w;
+                w.x = (uint32_t)x[g]; w.y = (uint32_t)((uint64_t)x[g] >> 32);
+                *(gptr<u32x2_a4>)(p + g * 8) = w;
+            } else {
+                *(gptr<uint32_t>)(p + g * 4) = (uint32_t)x[g];
+            }
+        }
+    }
+}
+
+// One tile [t0, t0 + n) of an item, by one wavefront.
+template <int ELEM>
+__device__ inline void ld_wave_tile(const LdDict<ELEM>& dict, const LdItem& it, uint64_t t0, uint32_t n, u32x4* tab, uint32_t tab_cap) {
+    typedef typename LdElem<ELEM>::T T;
+    constexpr int G = 16 / ELEM;                 // values per lane and step: one 16-byte store
+    constexpr uint32_t STEP = 64 * G;            // values per wavefront and step
+    const DevPage& pg = *it.pg;
+    DevResult* res = it.res;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t bw = it.bw;
+    const uint32_t mask = bw >= 32 ? 0xffffffffu : ((1u << bw) - 1);
+    gptr<const uint8_t> src = as_global(pg.src);
+    const uint8_t* lim = (const uint8_t*)(((uintptr_t)(pg.src + pg.src_len) + 15) & ~(uintptr_t)15);
+    gptr<const Run> runs = as_global((const Run*)pg.runs);
+    const uint64_t end = t0 + n;
+
+    uint32_t n_stream = n;                       // values of the tile the stream holds; the rest are zero indexes
+    if (t0 >= it.total) n_stream = 0;
+    else if (end > it.total) n_stream = (uint32_t)(it.total - t0);
+
+    uint64_t r0 = 0;
+    Run first = it.only;
+    if (n_stream > 0 && it.n_runs > 1) {
+        r0 = as_global((const uint32_t*)pg.tile_run)[t0 / RLE_TILE];
+        first = load_run(runs, r0);
+    }
+    const uint64_t first_end = (uint64_t)first.out_start + (first.count_kind >> 1);
+    const bool single = n_stream > 0 && first_end >= t0 + n_stream;
+
+    if (single && (first.count_kind & 1)) {
+        // ---- inside one bit-packed run ----
+        const uint64_t k0 = t0 - first.out_start;
+        gptr<const uint8_t> packed = src + first.in_off;
+#pragma unroll 4
+        for (uint32_t j0 = 0; j0 < RLE_TILE; j0 += STEP) {
+            const uint32_t j = j0 + lane * G;
+            if (j0 >= n) break;
+            uint32_t v[G];
+#pragma unroll
+            for (int g = 0; g < G; g++) v[g] = 0;
+            if (j + G <= n_stream) {
+                read_fields<G>(packed, lim, (k0 + j) * bw, bw, mask, v);
+            } else {
+#pragma unroll
+                for (int g = 0; g < G; g++)
+                    if (j + g < n_stream) v[g] = (uint32_t)read_bits(packed, lim, (k0 + j + g) * bw) & mask;
+            }
+            if (j < n) {
+                T x[G];
+                ld_lookup<ELEM, G>(dict, res, t0 + j, v, x);
+                ld_store<ELEM, G>(pg, t0 + j, end, x);
+            }
+        }
+        return;
+    }
+    if (single) {
+        // ---- inside one repeated run: one look-up, then a fill (the zero-extended rest of the tile after it) ----
+        uint32_t v[1] = {first.value};
+        T x1[1];
+        ld_lookup<ELEM, 1>(dict, res, t0, v, x1);
+        T x[G];
+#pragma unroll
+        for (int g = 0; g < G; g++) x[g] = x1[0];
+        for (uint32_t j = lane * G; j < n_stream; j += STEP) ld_store<ELEM, G>(pg, t0 + j, t0 + n_stream, x);
+    } else if (n_stream > 0) {
+        // ---- several runs meet the tile: their entries go to the wavefront's table in LDS ----
+        const uint64_t avail = it.n_runs - r0;
+        const uint32_t nr = avail < tab_cap ? (uint32_t)avail : tab_cap;
+        for (uint32_t k = lane; k < nr; k += 64) tab[k] = *(gptr<const u32x4>)(runs + r0 + k);
+        ld_wave_sync();
+        uint32_t in_tile; // staged runs that start before the end of the tile's stream part
+        {
+            uint32_t lo = 0, hi = nr;
+            while (hi - lo > 1) {
+                const uint32_t mid = (lo + hi) >> 1;
+                if ((uint64_t)tab[mid].x < t0 + n_stream) lo = mid; else hi = mid;
+            }
+            in_tile = lo + 1;
+        }
+        const u32x4 last = tab[in_tile - 1];
+        const bool in_lds = (uint64_t)last.x + (last.w >> 1) >= t0 + n_stream;
+        for (uint32_t j0 = 0; j0 < n_stream; j0 += STEP) {
+            const uint32_t j = j0 + lane * G;
+            if (j >= n_stream) continue;
+            const uint64_t pos = t0 + j;
+            uint32_t v[G];
+#pragma unroll
+            for (int g = 0; g < G; g++) v[g] = 0;
+            if (in_lds) {
+                uint32_t lo = 0, hi = in_tile; // last staged run with out_start <= pos
+                while (hi - lo > 1) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    if ((uint64_t)tab[mid].x <= pos) lo = mid; else hi = mid;
+                }
+                u32x4 e = tab[lo];
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    const uint64_t q = pos + g;
+                    if (j + g >= n_stream) break;
+                    if (q >= (uint64_t)e.x + (e.w >> 1) && lo + 1 < in_tile) e = tab[++lo]; // every run holds at least one value
+                    v[g] = (e.w & 1) ? (uint32_t)read_bits(src + e.y, lim, (q - e.x) * bw) & mask : e.z;
+                }
+            } else {
+                // more runs than the table holds: bisection over the run table in memory
+#pragma unroll
+                for (int g = 0; g < G; g++) {
+                    const uint64_t q = pos + g;
+                    if (j + g >= n_stream) break;
+                    uint64_t lo = r0, hi = it.n_runs;
+                    while (hi - lo > 1) {
+                        const uint64_t mid = (lo + hi) >> 1;
+                        if ((uint64_t)runs[mid].out_start <= q) lo = mid; else hi = mid;
+                    }
+                    const Run rr = load_run(runs, lo);
+                    v[g] = (rr.count_kind & 1) ? (uint32_t)read_bits(src + rr.in_off, lim, (q - rr.out_start) * bw) & mask : rr.value;
+                }
+            }
+            T x[G];
+            // positions past the stream inside this step are written by the tail below
+            uint32_t valid = n_stream - j < (uint32_t)G ? n_stream - j : (uint32_t)G;
+            ld_lookup<ELEM, G>(dict, res, pos, v, x);
+            ld_store<ELEM, G>(pg, pos, pos + valid, x);
+        }
+        ld_wave_sync(); // the table is rewritten for the next tile only after these reads
+    }
+    // ---- the zero-extended rest: index 0 ----
+    if (n_stream < n) {
+        uint32_t v[1] = {0};
+        T x1[1];
+        // an empty dictionary fails at the first such position
+        ld_lookup<ELEM, 1>(dict, res, t0 + n_stream, v, x1);
+        for (uint32_t j = n_stream + lane; j < n; j += 64) ld_store<ELEM, 1>(pg, t0 + j, end, x1);
+    }
+}
+
+// A tile as a wavefront holds it between looking it up and decoding it (all wave-uniform, and
+// small: two of these and the item of the tile looked up last live in scalar registers).
+struct LdTile {
+    uint64_t u;                 // the tile's number in the family's grid
+    uint32_t wi;                // position of its item in the family list
+    uint32_t n;                 // values to write; 0: nothing
+    bool fast;                  // a whole tile inside one bit-packed run: its packed words are fetched a tile ahead
+    // fast tiles only:
+    gptr<const uint8_t> packed; // byte of the run's packed data that holds the tile's first field
+    gptr<uint8_t> dst;          // where the tile's first value goes
+    DevResult* res;
+    uint64_t t0;                // first value of the tile in its page
+    uint32_t s0, bw;            // bit of the first field inside that byte; field width
+};
+
+// Position inside the tile of the p-th pair of values of a lane: sixteen pairs per lane and tile
+// (eight per half tile), laid out so that the values of one 16-byte store are consecutive.
+template <int ELEM>
+__device__ inline uint32_t ld_pair_pos(uint32_t p, uint32_t lane) {
+    return ELEM == 8 ? p * 128 + lane * 2 : (p >> 1) * 256 + lane * 4 + (p & 1) * 2;
+}
+constexpr uint32_t LD_PAIRS = RLE_TILE / (64 * 2) / 2; // pairs per lane and HALF tile: what is fetched ahead at a time
+constexpr uint32_t LD_FAST_MAX_BW = 28; // two fields and up to seven bits of shift fit one 8-byte load
+
+// A page that is a width byte and ONE bit-packed run up to its last byte -- what indexes without
+// repeats come as -- needs no run table: everything the decode wants to know stands in its
+// first bytes.  Same rules as the index (rle.go:352-419, rle/dictionary.go:30-37), cut down to
+// this shape; anything else answers false and goes through the index.
+__device__ inline bool ld_simple_page(const DevPage& pg, uint32_t& bw, uint64_t& total, uint32_t& in_off) {
+    if (pg.src_len < 3 || pg.src_len > 0xffffffffull) return false;
+    const uint8_t* lim = (const uint8_t*)(((uintptr_t)(pg.src + pg.src_len) + 15) & ~(uintptr_t)15);
+    const uint64_t w = ld_uniform(read_bits(as_global(pg.src), lim, 0));
+    bw = (uint32_t)w & 0xff;
+    if (bw > 32) return false;
+    const uint32_t a0 = (uint32_t)(w >> 8);
+    uint32_t u, k;
+    if (!(a0 & 0x80)) { u = a0 & 0x7f; k = 1; }
+    else if (!(a0 & 0x8000)) { u = (a0 & 0x7f) | ((a0 >> 1) & 0x3f80); k = 2; }
+    else if (!(a0 & 0x800000)) { u = (a0 & 0x7f) | ((a0 >> 1) & 0x3f80) | ((a0 >> 2) & 0x1fc000); k = 3; }
+    else if (!(a0 & 0x80000000u)) { u = (a0 & 0x7f) | ((a0 >> 1) & 0x3f80) | ((a0 >> 2) & 0x1fc000) | ((a0 >> 3) & 0xfe00000); k = 4; }
+    else return false;
+    const uint64_t count = u >> 1;
+    if (!(u & 1) || count == 0 || count * 8 > MAX_TOTAL) return false;
+    if (1 + k + count * bw != pg.src_len) return false;
+    total = count * 8;
+    in_off = 1 + k;
+    return true;
+}
+
+// Is the page's run table the work of the chunked kernels (rle_chunk_resolve / rle_chunk_emit)?
+__device__ inline bool ld_chunk_indexed(const DevPage& pg, const uint32_t* __restrict__ pk_flag) {
+    return pg.ck_index >= 0 && pk_flag[pg.ck_index] == 0;
+}
+
+// Makes `it` the item that holds tile u (reloaded only when that is another one than before; `wi`
+// follows the family list forwards) and returns how many values of the tile are to be written.
+// The wavefront that takes an item's first tile also writes the item's result fields.
+template <int ELEM>
+__device__ inline uint32_t ld_item_of(const DevPage* __restrict__ pages, DevResult* __restrict__ results, const uint32_t* __restrict__ items,
+                                      const uint64_t* __restrict__ tile_prefix, const uint32_t* __restrict__ pk_flag, uint64_t u,
+                                      LdItem& it, uint32_t& wi) {
+    const uint32_t lane = threadIdx.x & 63;
+    bool simple = false;
+    if (it.pg == nullptr || u >= it.tile_hi) {
+        while (tile_prefix[wi + 1] <= u) wi++;
+        const uint32_t item = items[wi];
+        it.pg = &pages[item];
+        it.res = &results[item];
+        it.tile_lo = tile_prefix[wi];
+        it.tile_hi = tile_prefix[wi + 1];
+        uint32_t in_off = 0;
+        simple = !ld_chunk_indexed(*it.pg, pk_flag) && ld_simple_page(*it.pg, it.bw, it.total, in_off);
+        if (simple) {
+            it.n_runs = 1;
+            it.only.out_start = 0; it.only.in_off = in_off; it.only.value = 0; it.only.count_kind = ((uint32_t)it.total << 1) | 1u;
+        } else { // what the index left (this workgroup's own wavefronts, or the chunked kernels before this launch)
+            gptr<const DevResult> r = as_global((const DevResult*)it.res);
+            it.total = ld_uniform(r->total);
+            it.n_runs = ld_uniform(r->n_runs);
+            it.bw = ld_uniform((uint32_t)r->bw);
+            const u32x4 f = *(gptr<const u32x4>)(r->first);
+            it.only.out_start = ld_uniform(f.x); it.only.in_off = ld_uniform(f.y); it.only.value = ld_uniform(f.z); it.only.count_kind = ld_uniform(f.w);
+        }
+        it.n_out = output_count(*it.pg, it.total, true);
+    }
+    const DevPage& pg = *it.pg;
+    const uint64_t tile = u - it.tile_lo;
+    uint64_t n_out = it.n_out;
+    const uint64_t fit = pg.dst_cap / ELEM;
+    if (tile == 0 && lane == 0) {
+        // (tile 0 is the first tile of its item this wavefront sees, so `simple` was computed above)
+        DevResult* res = it.res;
+        if (simple) {
+            res->status = PQD_OK;
+            res->bw = (int32_t)it.bw;
+            res->arg = 0;
+            res->n_runs = 1;
+            res->total = it.total;
+            res->consumed = pg.src_len;
+        }
+        const bool too_small = n_out > fit;
+        const uint64_t w = too_small ? fit : n_out;
+        res->out_values = w;
+        res->out_bytes = w * ELEM;
+        res->need_bytes = too_small ? n_out * ELEM : 0; // the index may still be writing the status: kept apart from it
+    }
+    if (n_out > fit) n_out = fit;
+    const uint64_t t0 = tile * RLE_TILE;
+    return t0 >= n_out ? 0u : (n_out - t0 < RLE_TILE ? (uint32_t)(n_out - t0) : RLE_TILE);
+}
+
+// Looks tile u up and says whether the fast form applies.
+template <int ELEM>
+__device__ inline void ld_setup(const DevPage* __restrict__ pages, DevResult* __restrict__ results, const uint32_t* __restrict__ items,
+                                const uint64_t* __restrict__ tile_prefix, const uint32_t* __restrict__ pk_flag, uint64_t u, LdItem& it,
+                                uint32_t& wi, bool allow_fast, LdTile& out) {
+    out.n = ld_item_of<ELEM>(pages, results, items, tile_prefix, pk_flag, u, it, wi);
+    out.u = u;
+    out.wi = wi;
+    out.fast = false;
+    const DevPage& pg = *it.pg;
+    const uint64_t t0 = (u - it.tile_lo) * RLE_TILE;
+    // the first run of the page covers the whole tile (the usual page has one run; tiles of later runs take the slow form)
+    const Run& f = it.only;
+    if (allow_fast && out.n == RLE_TILE && (f.count_kind & 1) && it.bw <= LD_FAST_MAX_BW &&
+        (uint64_t)f.out_start + (f.count_kind >> 1) >= t0 + RLE_TILE && t0 + RLE_TILE <= it.total) {
+        const uint64_t bit0 = (t0 - f.out_start) * it.bw;
+        const uint64_t first_byte = (uint64_t)f.in_off + (bit0 >> 3);
+        const uint64_t last_load_end = first_byte + ((7 + (uint64_t)RLE_TILE * it.bw) >> 3) + 8;
+        const uint64_t lim = (((uintptr_t)(pg.src + pg.src_len) + 15) & ~(uintptr_t)15) - (uintptr_t)pg.src;
+        if (last_load_end <= lim) {
+            out.fast = true;
+            out.packed = as_global(pg.src) + first_byte;
+            out.dst = as_global(pg.dst) + t0 * ELEM;
+            out.res = it.res;
+            out.t0 = t0;
+            out.s0 = (uint32_t)bit0 & 7;
+            out.bw = it.bw;
+        }
+    }
+}
+
+template <int ELEM>
+__device__ inline void ld_prefetch(const LdTile& tl, uint32_t half, uint64_t (&w)[LD_PAIRS]) {
+    const uint32_t lane = threadIdx.x & 63;
+#pragma unroll
+    for (uint32_t p = 0; p < LD_PAIRS; p++) {
+        const uint32_t bit = tl.s0 + ld_pair_pos<ELEM>(half * LD_PAIRS + p, lane) * tl.bw; // < 8 + 2048 * 28
+        w[p] = *(gptr<const u64_a1>)(tl.packed + (bit >> 3));
+    }
+}
+
+// Half of a fast tile out of its prefetched words: unpack, look up, store.  Straight-line code:
+// every lane reads LDS (at entry 0 when its index lies elsewhere) and, when part of the
+// dictionary stayed in memory (PART), memory too (again at entry 0 when the index lies
+// elsewhere: those lanes share one cache line); an index outside the dictionary yields zero
+// and the first such position of the lane is reported once, after the stores.
+template <int ELEM, bool PART>
+__device__ inline void ld_fast_half(const LdDict<ELEM>& dict, const LdTile& tl, uint32_t half, const uint64_t (&w)[LD_PAIRS]) {
+    typedef typename LdElem<ELEM>::T T;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t bw = tl.bw;
+    const uint32_t mask = (1u << bw) - 1; // bw <= 28 here
+    const uint32_t len = dict.len > 0xffffffffull ? 0xffffffffu : (uint32_t)dict.len; // indexes have at most 28 bits
+    uint32_t bad = 0xffffffffu; // first position of this lane, inside the tile, whose index is outside the dictionary
+    auto look = [&](uint32_t idx, uint32_t j) -> T {
+        const bool in_lds = idx < dict.lds_n;
+        T x = dict.lds[in_lds ? idx : 0];
+        if (PART) {
+            const bool in_mem = !in_lds && idx < len;
+            const T m = dict.mem[in_mem ? idx : 0];
+            x = in_mem ? m : x;
+        }
+        const bool ok = idx < len;
+        bad = ok || bad < j ? bad : j;
+        return ok ? x : (T)0;
+    };
+    if (ELEM == 8) {
+#pragma unroll
+        for (uint32_t p = 0; p < LD_PAIRS; p++) {
+            const uint32_t j = ld_pair_pos<8>(half * LD_PAIRS + p, lane);
+            const uint32_t s = (tl.s0 + j * bw) & 7;
+            u64x2_a8 o;
+            o.x = look((uint32_t)(w[p] >> s) & mask, j);
+            o.y = look((uint32_t)(w[p] >> (s + bw)) & mask, j + 1);
+            *(gptr<u64x2_a8>)(tl.dst + (uint64_t)j * 8) = o;
+        }
+    } else {
+#pragma unroll
+        for (uint32_t p = 0; p < LD_PAIRS; p += 2) {
+            const uint32_t j = ld_pair_pos<4>(half * LD_PAIRS + p, lane);
+            const uint32_t s0 = (tl.s0 + j * bw) & 7, s1 = (tl.s0 + (j + 2) * bw) & 7;
+            u32x4_a4 o;
+            o.x = (uint32_t)look((uint32_t)(w[p] >> s0) & mask, j);
+            o.y = (uint32_t)look((uint32_t)(w[p] >> (s0 + bw)) & mask, j + 1);
+            o.z = (uint32_t)look((uint32_t)(w[p + 1] >> s1) & mask, j + 2);
+            o.w = (uint32_t)look((uint32_t)(w[p + 1] >> (s1 + bw)) & mask, j + 3);
+            *(gptr<u32x4_a4>)(tl.dst + (uint64_t)j * 4) = o;
+        }
+    }
+    if (bad != 0xffffffffu) ld_record_bad(tl.res, dict.launch, tl.t0 + bad);
+}
+
+template <int ELEM, bool PART>
+__global__ __launch_bounds__(LDT) void rle_dict_lds_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                           const uint32_t* __restrict__ items, uint32_t n_items,
+                                                           const uint64_t* __restrict__ tile_prefix, uint64_t n_tiles,
+                                                           const uint32_t* __restrict__ wg_item, const uint32_t* __restrict__ seg_last,
+                                                           const uint32_t* __restrict__ pk_flag, uint32_t launch,
+                                                           uint32_t dict_cap_bytes, uint32_t tab_cap) {
+    typedef typename LdElem<ELEM>::T T;
+    extern __shared__ __attribute__((aligned(16))) uint8_t ld_shared[];
+    const uint32_t tid = threadIdx.x, wave = ld_uniform(tid >> 6);
+    u32x4* tab = reinterpret_cast<u32x4*>(ld_shared + dict_cap_bytes) + (size_t)wave * tab_cap;
+    // this workgroup's stretch of the family's tiles, and the items its first and last tile belong to
+    const uint64_t T0 = n_tiles * blockIdx.x / gridDim.x, T1 = n_tiles * (blockIdx.x + 1) / gridDim.x;
+    uint32_t li = wg_item[2 * blockIdx.x];
+    // ---- the run tables of this workgroup's pages: a wavefront per page, in LDS that the dictionary
+    // takes over afterwards.  Pages that are one bit-packed run need none, pages the chunked kernels
+    // indexed have theirs.  A page that reaches into a neighbouring workgroup's stretch is indexed
+    // there as well: both write the same table, and neither waits for the other. ----
+    if (T0 < T1) {
+        const uint32_t li_last = wg_item[2 * blockIdx.x + 1];
+        uint32_t* ring = reinterpret_cast<uint32_t*>(ld_shared + (size_t)wave * LD_INDEX_BYTES);
+        ICtl& ctl = *reinterpret_cast<ICtl*>(ld_shared + (size_t)wave * LD_INDEX_BYTES + IRING_BYTES);
+        for (uint32_t k = li + wave; k <= li_last; k += LD_WAVES) {
+            const uint32_t item = items[k];
+            const DevPage& pg = pages[item];
+            uint32_t bw0, off0;
+            uint64_t total0;
+            if (ld_chunk_indexed(pg, pk_flag) || ld_simple_page(pg, bw0, total0, off0)) continue;
+            rle_index_page<false>(ring, ctl, pg, &results[item], tid & 63);
+        }
+    }
+    __syncthreads(); // the tables are in place (and the rings free) before any wavefront looks a tile up
+    uint64_t t = T0;
+    while (t < T1) {
+        // ---- a segment: the tiles of consecutive items that share one dictionary ----
+        while (tile_prefix[li + 1] <= t) li++;
+        const uint64_t seg_hi = tile_prefix[seg_last[li] + 1];
+        const uint64_t seg_end = seg_hi < T1 ? seg_hi : T1;
+        const DevPage& p0 = pages[items[li]];
+        LdDict<ELEM> dict;
+        dict.lds = reinterpret_cast<const T*>(ld_shared);
+        dict.mem = (gptr<const T>)as_global(p0.dict);
+        dict.len = p0.dict_len;
+        dict.lds_n = dict.len < dict_cap_bytes / ELEM ? (uint32_t)dict.len : dict_cap_bytes / ELEM;
+        dict.launch = launch;
+        // the fast form reads entry 0 for lanes whose index lies elsewhere: there has to be one, and all of
+        // the dictionary has to be in LDS unless this is the kernel that also looks in memory
+        const bool allow_fast = dict.len > 0 && (PART || dict.lds_n == dict.len);
+        // ---- this wavefront's first tile: looked up, and its packed words asked for, while the dictionary comes in ----
+        LdItem it;
+        it.pg = nullptr; it.res = nullptr; it.total = it.n_runs = it.n_out = 0; it.tile_lo = it.tile_hi = 0; it.bw = 0;
+        it.only.out_start = it.only.in_off = it.only.value = it.only.count_kind = 0;
+        uint32_t wi = li;
+        uint64_t u = t + wave;
+        const bool have = u < seg_end;
+        LdTile cur;
+        uint64_t w_a[LD_PAIRS], w_b[LD_PAIRS]; // packed words of the first / second half of a fast tile
+#pragma unroll
+        for (uint32_t p = 0; p < LD_PAIRS; p++) w_a[p] = w_b[p] = 0;
+        cur.fast = false; cur.n = 0; cur.u = 0; cur.wi = 0;
+        if (have) {
+            ld_setup<ELEM>(pages, results, items, tile_prefix, pk_flag, u, it, wi, allow_fast, cur);
+            if (cur.fast) ld_prefetch<ELEM>(cur, 0, w_a);
+        }
+        {
+            // The dictionary's bytes, 16 per thread and load, U loads in flight per thread.  Offsets past
+            // the last whole 16 bytes are pulled back onto them (threads then copy the same bytes
+            // twice): no branch around a load, so all of a pass's loads are in flight together.
+            const uint32_t bytes = dict.lds_n * ELEM, body = bytes & ~15u;
+            gptr<const uint8_t> g = as_global(p0.dict);
+            constexpr uint32_t U = 4, PASS = U * LDT * 16;
+            const uint32_t last = body >= 16 ? body - 16 : 0;
+            u32x4_a1 wd[U];
+            uint32_t at[U];
+            if (body >= 16) {
+#pragma unroll
+                for (uint32_t k = 0; k < U; k++) {
+                    const uint32_t c = tid * 16 + k * LDT * 16;
+                    at[k] = c < last ? c : last;
+                    wd[k] = *(gptr<const u32x4_a1>)(g + at[k]);
+                }
+            }
+            __syncthreads(); // nobody still reads the dictionary of the segment before
+            if (body >= 16) {
+#pragma unroll
+                for (uint32_t k = 0; k < U; k++) *reinterpret_cast<u32x4*>(ld_shared + at[k]) = wd[k];
+                for (uint32_t base = PASS; base < body; base += PASS) {
+#pragma unroll
+                    for (uint32_t k = 0; k < U; k++) {
+                        const uint32_t c = base + tid * 16 + k * LDT * 16;
+                        at[k] = c < last ? c : last;
+                        wd[k] = *(gptr<const u32x4_a1>)(g + at[k]);
+                    }
+#pragma unroll
+                    for (uint32_t k = 0; k < U; k++) *reinterpret_cast<u32x4*>(ld_shared + at[k]) = wd[k];
+                }
+            }
+            for (uint32_t b = body + tid; b < bytes; b += LDT) ld_shared[b] = g[b];
+        }
+        __syncthreads();
+        // ---- the wavefronts take the segment's tiles in turn, each on its own.  First the fast ones: the
+        // packed words of half a tile are asked for before the half tile before it is decoded, so that no
+        // load waits behind stores ----
+        bool any_slow = false;
+        if (have) {
+            for (;;) {
+                const uint64_t un = u + LD_WAVES;
+                const bool more = un < seg_end;
+                LdTile nxt;
+                nxt.fast = false; nxt.n = 0; nxt.u = 0; nxt.wi = 0;
+                if (more) ld_setup<ELEM>(pages, results, items, tile_prefix, pk_flag, un, it, wi, allow_fast, nxt);
+                if (cur.fast) {
+                    ld_prefetch<ELEM>(cur, 1, w_b);
+                    ld_fast_half<ELEM, PART>(dict, cur, 0, w_a);
+                    if (nxt.fast) ld_prefetch<ELEM>(nxt, 0, w_a);
+                    ld_fast_half<ELEM, PART>(dict, cur, 1, w_b);
+                } else {
+                    any_slow = any_slow || cur.n > 0;
+                    if (nxt.fast) ld_prefetch<ELEM>(nxt, 0, w_a);
+                }
+                if (!more) break;
+                cur = nxt;
+                u = un;
+            }
+        }
+        // ---- then whatever is left: tiles that several runs meet, that lie in a repeated run, partial
+        // tiles, zero-extended ones (a pass of its own, so that the loop above carries none of this code's state) ----
+        if (any_slow) {
+            uint32_t wj = li;
+            for (uint64_t v = t + wave; v < seg_end; v += LD_WAVES) {
+                LdTile tl;
+                LdItem it2;
+                it2.pg = nullptr; it2.res = nullptr; it2.total = it2.n_runs = it2.n_out = 0; it2.tile_lo = it2.tile_hi = 0; it2.bw = 0;
+                it2.only.out_start = it2.only.in_off = it2.only.value = it2.only.count_kind = 0;
+                ld_setup<ELEM>(pages, results, items, tile_prefix, pk_flag, v, it2, wj, allow_fast, tl);
+                if (!tl.fast && tl.n > 0) ld_wave_tile<ELEM>(dict, it2, (v - it2.tile_lo) * RLE_TILE, tl.n, tab, tab_cap);
+            }
+        }
+        t = seg_end;
+    }
+}
+
 } // namespace
+
+// Largest dynamic LDS allocation a workgroup of rle_dict_lds_kernel may ask for.
+constexpr uint32_t LD_MAX_LDS = 160 * 1024 - 1024;
+constexpr uint32_t LD_MIN_TAB = 32;    // run-table entries per wavefront, at least / at most
+constexpr uint32_t LD_MAX_TAB = 512;
+
+bool rle_dict_lds_init() {
+    // dynamic LDS above the default limit has to be asked for once per kernel
+    static const bool ok = [] {
+        bool r = true;
+        for (const void* fn : {reinterpret_cast<const void*>(&rle_dict_lds_kernel<8, false>), reinterpret_cast<const void*>(&rle_dict_lds_kernel<8, true>),
+                               reinterpret_cast<const void*>(&rle_dict_lds_kernel<4, false>), reinterpret_cast<const void*>(&rle_dict_lds_kernel<4, true>)})
+            r = r && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LD_MAX_LDS) == hipSuccess;
+        (void)hipGetLastError();
+        return r;
+    }();
+    return ok;
+}
+
+uint32_t rle_dict_lds_capacity() { return LD_MAX_LDS - LD_WAVES * LD_MIN_TAB * (uint32_t)sizeof(Run); }
+
+LdsPlan rle_dict_lds_plan(uint64_t n_tiles, uint64_t max_dict_bytes, uint64_t cap_bytes, uint32_t n_cus) {
+    LdsPlan p;
+    // LDS: the dictionary (or the part of it that fits), then a run table per wavefront from what is left
+    p.dict_bytes = (uint32_t)std::min<uint64_t>((max_dict_bytes + 15) & ~15ull, rle_dict_lds_capacity());
+    if (cap_bytes > 0 && p.dict_bytes > cap_bytes) p.dict_bytes = (uint32_t)cap_bytes;
+    p.dict_bytes &= ~15u;
+    if (p.dict_bytes < 16) p.dict_bytes = 16;
+    p.part = max_dict_bytes > p.dict_bytes;
+    p.tab_cap = std::min((LD_MAX_LDS - p.dict_bytes) / (LD_WAVES * (uint32_t)sizeof(Run)), LD_MAX_TAB);
+    p.lds_bytes = std::max(p.dict_bytes + LD_WAVES * p.tab_cap * (uint32_t)sizeof(Run), LD_WAVES * LD_INDEX_BYTES);
+    // workgroups: one per CU (sixteen wavefronts; their registers leave no room for a second), fewer when there
+    // is little work: loading the dictionary has to pay
+    uint64_t grid = n_cus;
+    const uint64_t by_work = (n_tiles + 7) / 8;
+    if (grid > by_work) grid = by_work;
+    p.grid = (uint32_t)std::max<uint64_t>(grid, 1);
+    return p;
+}
+
+void launch_rle_dict_lds(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
+                         const uint64_t* tile_prefix, uint64_t n_tiles, int32_t elem, const LdsPlan& plan, const uint32_t* wg_item,
+                         const uint32_t* seg_last, const uint32_t* pk_flag, uint32_t launch, hipStream_t stream) {
+    if (n_items == 0 || n_tiles == 0) return;
+#define PQD_LDS_LAUNCH(E, P)                                                                                                   \
+    hipLaunchKernelGGL((rle_dict_lds_kernel<E, P>), dim3(plan.grid), dim3(LDT), plan.lds_bytes, stream, pages, results, items, \
+                       n_items, tile_prefix, n_tiles, wg_item, seg_last, pk_flag, launch, plan.dict_bytes, plan.tab_cap)
+    if (elem == 8) { if (plan.part) PQD_LDS_LAUNCH(8, true); else PQD_LDS_LAUNCH(8, false); }
+    else { if (plan.part) PQD_LDS_LAUNCH(4, true); else PQD_LDS_LAUNCH(4, false); }
+#undef PQD_LDS_LAUNCH
+}
 
 void launch_rle_index(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, const uint32_t* pk_flag,
                       hipStream_t stream) {

@@ -11,5 +11,5 @@ q = (f"select s.display_name, d.grid_size_x, d.workgroup_size_x, count(*), avg(d
      f"from {kd} d join {sym} s on d.kernel_id=s.id group by s.display_name, d.grid_size_x order by min(d.start)")
 print(f"{'kernel':50s} {'grid':>10s} {'wg':>5s} {'calls':>6s} {'avg us':>9s} {'min us':>9s}")
 for name, grid, wg, n, avg, mn in c.execute(q):
-    name = name.split("(")[0].replace("pqd::(anonymous namespace)::", "")
+    name = name.replace("pqd::(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     print(f"{name[:50]:50s} {grid:10d} {wg:5d} {n:6d} {avg:9.1f} {mn:9.1f}")

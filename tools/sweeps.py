@@ -145,7 +145,7 @@ def rle_int32_page(idx, bw):
 
 def dictionary(rng):
     n = 262144
-    for bw in (8, 12, 16, 20):
+    for bw in (8, 10, 12, 14, 15, 16, 17, 20):
         d = rng.integers(-2**62, 2**62, size=1 << bw, dtype=np.int64)
         idx = [rng.integers(0, 1 << bw, size=n, dtype=np.int64).astype(np.int32) for _ in range(8)]
         pages = [bytes([bw]) + uvarint(((n // 8) << 1) | 1) + pack_lsb(v, bw) for v in idx]
