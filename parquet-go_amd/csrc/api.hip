@@ -107,11 +107,10 @@ constexpr uint64_t RLE_CHUNKED_MIN_BYTES_FEW = 4096; // ... unless the batch hol
 constexpr size_t RLE_CHUNKED_FEW_PAGES = 128;
 constexpr int32_t RLE_FAMILY[RLE_GRIDS] = {FAM_RLE, FAM_RLE_BYTES, FAM_RLE_DICT8, FAM_RLE_DICT4, FAM_RLE_LDS8, FAM_RLE_LDS4};
 inline bool is_lds_family(int32_t family) { return family == FAM_RLE_LDS8 || family == FAM_RLE_LDS4; }
-// An LDS-resident dictionary pays when the family decodes at least this many tiles of 2048 values (below that the
-// copies of the dictionary, one per workgroup, outweigh what the gathers save) ...
-constexpr uint64_t LDS_DICT_MIN_TILES = 256;
-// ... and the dictionary is not much larger than what a workgroup can hold
-constexpr uint64_t LDS_DICT_DEFAULT_MAX_BYTES = 1ull << 20;
+// Largest dictionary that goes through the persistent kernels by default (beyond what LDS holds, the first
+// part of a dictionary is kept there and the rest read from memory: measured faster than the tile-per-workgroup
+// kernel up to 8 MB dictionaries at least)
+constexpr uint64_t LDS_DICT_DEFAULT_MAX_BYTES = 1ull << 30;
 inline int rle_grid(int32_t family) {
     for (int g = 0; g < RLE_GRIDS; g++) if (RLE_FAMILY[g] == family) return g;
     return -1;
@@ -377,10 +376,31 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
                 return d.family == from && d.fused && (d.dst_stride == 0 || d.dst_stride == d.elem_width) &&
                        d.dict_len * (uint64_t)d.elem_width <= ctx->dict_lds_max_bytes;
             };
+            // What the path costs: every persistent workgroup copies the dictionary of every stretch of pages
+            // it meets into LDS.  It pays while those copies stay below the bytes decoded.
             uint64_t tiles = 0;
             for (const DevPage& d : b->items)
                 if (candidate(d)) tiles += rle_steps_of(d);
-            if (tiles == 0 || (ctx->dict_lds == 1 && tiles < LDS_DICT_MIN_TILES)) continue;
+            if (tiles == 0) continue;
+            if (ctx->dict_lds == 1) {
+                const uint64_t grid = std::max<uint64_t>(1, std::min<uint64_t>(ctx->n_cus, (tiles + 7) / 8));
+                const uint64_t cap = rle_dict_lds_capacity();
+                uint64_t copied = 0, at = 0, wg_seen = ~0ull;
+                const void* last_dict = nullptr;
+                for (const DevPage& d : b->items) {
+                    if (!candidate(d)) continue;
+                    const uint64_t steps = rle_steps_of(d), bytes = std::min<uint64_t>(d.dict_len * (uint64_t)d.elem_width, cap);
+                    // workgroups whose stretch [tiles * w / grid, tiles * (w + 1) / grid) meets this page's tiles [at, at + steps)
+                    const uint64_t w0 = at * grid / tiles, w1 = ((at + steps) * grid - 1) / tiles;
+                    uint64_t n = w1 - w0 + 1;
+                    if (d.dict == last_dict && w0 == wg_seen) n--; // the page before left this dictionary in the first of them
+                    copied += n * bytes;
+                    last_dict = d.dict;
+                    wg_seen = w1;
+                    at += steps;
+                }
+                if (copied > tiles * RLE_TILE * (uint64_t)(from == FAM_RLE_DICT8 ? 8 : 4)) continue;
+            }
             for (DevPage& d : b->items)
                 if (candidate(d)) {
                     d.family = to;
