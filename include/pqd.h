@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PQD_ABI_VERSION 1
+#define PQD_ABI_VERSION 2
 
 typedef struct pqd_ctx pqd_ctx;     /* one per process and device */
 typedef struct pqd_batch pqd_batch; /* a prepared set of pages */
@@ -69,7 +69,16 @@ void pqd_ctx_destroy(pqd_ctx* ctx);
  * Dictionary.Lookup (dictionary.go:64-69, dictionary_amd64.go:36-58) fused in
  * one kernel; `kind` then names the value type (INT32/INT64/FLOAT/DOUBLE/INT96)
  * and `dst_stride` the distance between rows in bytes (0 = dense;
- * sparse.Array's stride, sparse/array.go:33-37).
+ * sparse.Array's stride, sparse/array.go:33-37).  Dictionaries of the other
+ * types are looked up in the same pass and come out in the layout the Decode
+ * methods produce (the reference's lookupString hands out string headers that
+ * point into the dictionary, dictionary_purego.go:40-52): kind BYTE_ARRAY with
+ * `dict` = the dictionary's value bytes and `dict_offsets` = its dict_len + 1
+ * offsets (what PLAIN's DecodeByteArray leaves of the dictionary page) yields
+ * values in `dst` and num_values + 1 `offsets`; FIXED_LEN_BYTE_ARRAY of any
+ * `bit_width` yields dense values; BOOLEAN with `dict` = the dictionary's
+ * packed bits yields one byte, 0 or 1, per value (booleanDictionary.lookup,
+ * dictionary_boolean.go:93-98).
  *
  * `num_values` >= 0 cuts the output to that many values the way the callers
  * do (column.go:940-945, dictionary.go:136-162); -1 returns everything the
@@ -84,6 +93,7 @@ typedef struct pqd_page {
     uint64_t    offsets_cap; /* entries */
     const void* dict;     /* optional dictionary values (device) */
     uint64_t    dict_len; /* entries */
+    const uint32_t* dict_offsets; /* BYTE_ARRAY dictionaries: dict_len + 1 offsets into dict (device) */
     int64_t     num_values;
     int32_t     encoding; /* pqd_encoding */
     int32_t     kind;     /* pqd_kind */
@@ -174,6 +184,22 @@ int pqd_dict_lookup(pqd_dict* dict, const int32_t* indexes, uint64_t n, void* ro
 int pqd_dict_lookup_device(pqd_ctx* ctx, const void* dict_dev, uint64_t dict_len, uint32_t width,
                            const int32_t* indexes_dev, uint64_t n, void* rows_dev, uint64_t stride,
                            int64_t* status_dev, void* hip_stream);
+
+/* Dictionary.Lookup for BYTE_ARRAY, FIXED_LEN_BYTE_ARRAY (any `width`) and
+ * BOOLEAN dictionaries (byteArrayDictionary / fixedLenByteArrayDictionary
+ * lookupString, dictionary_purego.go:40-52; booleanDictionary.lookup,
+ * dictionary_boolean.go:93-98) on device pointers, enqueued on `hip_stream`.
+ * The values come out as the Decode methods lay them out: BYTE_ARRAY bytes
+ * back to back in dst with n + 1 offsets in offsets_dev, FIXED_LEN_BYTE_ARRAY
+ * dense, BOOLEAN (dictionary = packed bits) one byte per value.  `status_dev`
+ * points to three int64 in device memory: {status, arg, bytes written}:
+ * PQD_ERR_INDEX_OUT_OF_BOUNDS with the position of the first bad index,
+ * PQD_ERR_DST_TOO_SMALL / PQD_ERR_OFFSETS_TOO_SMALL with the size to come back
+ * with (nothing is written to dst then). */
+int pqd_dict_lookup_bytes_device(pqd_ctx* ctx, int32_t kind, const void* dict_dev, const uint32_t* dict_offsets_dev,
+                                 uint64_t dict_len, uint32_t width, const int32_t* indexes_dev, uint64_t n, void* dst_dev,
+                                 uint64_t dst_cap, uint32_t* offsets_dev, uint64_t offsets_cap, int64_t* status_dev,
+                                 void* hip_stream);
 
 /* ---- definition and repetition levels, device-resident ------------------ */
 

@@ -71,7 +71,7 @@ class Page(C.Structure):
         ("src", C.c_void_p), ("src_len", C.c_uint64),
         ("dst", C.c_void_p), ("dst_cap", C.c_uint64),
         ("offsets", C.c_void_p), ("offsets_cap", C.c_uint64),
-        ("dict", C.c_void_p), ("dict_len", C.c_uint64),
+        ("dict", C.c_void_p), ("dict_len", C.c_uint64), ("dict_offsets", C.c_void_p),
         ("num_values", C.c_int64),
         ("encoding", C.c_int32), ("kind", C.c_int32), ("bit_width", C.c_int32), ("dst_stride", C.c_int32),
         ("status", C.c_int32), ("reserved", C.c_int32), ("status_arg", C.c_int64),
@@ -127,6 +127,7 @@ SYMBOLS = {
     "pqd_dict_destroy": (None, [_vp]),
     "pqd_dict_lookup": (_int, [_vp, _vp, _u64, _vp, _u64, _pi64]),
     "pqd_dict_lookup_device": (_int, [_vp, _vp, _u64, C.c_uint32, _vp, _u64, _vp, _u64, _vp, _vp]),
+    "pqd_dict_lookup_bytes_device": (_int, [_vp, C.c_int32, _vp, _vp, _u64, C.c_uint32, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp]),
     "pqd_levels_workspace_size": (_u64, [_u64]),
     "pqd_levels_count_equal_device": (_int, [_vp, _vp, _u64, C.c_uint8, _vp, _u64, _vp, _vp]),
     "pqd_optional_expand_device": (_int, [_vp, _vp, _u64, C.c_uint8, _vp, _u64, C.c_uint32, C.c_int32, _vp, _vp, _vp, _u64, _vp, _vp]),

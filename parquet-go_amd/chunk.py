@@ -56,7 +56,8 @@ def plan_pages(headers: List[PageHeader], chunk: bytes, chunk_dev: int, kind: in
 class Column:
     """A decoded column chunk, on the host: levels of every slot, the values that are present
     back to back (`values`, with `offsets` for byte arrays; dictionary indexes in `indexes`
-    when the dictionary holds byte arrays), and the dictionary if the chunk has one."""
+    only when a dictionary-encoded page came without a dictionary page), and the dictionary if the
+    chunk has one."""
     num_values: int
     definition_levels: Optional[np.ndarray]
     repetition_levels: Optional[np.ndarray]
@@ -106,7 +107,8 @@ def decode_chunk(ctx: Context, chunk: bytes, physical_type: str, type_length: in
         bufs = {}
         if part.role in (PART_REP, PART_DEF):
             bufs["dst"] = DeviceBuffer(n + 64, ctx.device)
-        elif byte_array and it.encoding not in (ENC.RLE_DICTIONARY,):
+        elif byte_array:
+            # (a dictionary-encoded page may need more than this: the batch says how much and is run again)
             bufs["dst"] = DeviceBuffer(max(4 * h.uncompressed_page_size, 4096), ctx.device)
             bufs["offsets"] = DeviceBuffer(4 * (n + 8), ctx.device)
             it.offsets, it.offsets_cap = bufs["offsets"].ptr, n + 1
@@ -119,7 +121,7 @@ def decode_chunk(ctx: Context, chunk: bytes, physical_type: str, type_length: in
 
     col = Column(0, None, None, headers=headers)
     # ---- the dictionary page first: data pages look their values up in it ----
-    dict_buf = None
+    dict_buf = dict_off = None
     dict_n = 0
     for it, part in zip(items, parts):
         if part.role != PART_DICT:
@@ -131,15 +133,19 @@ def decode_chunk(ctx: Context, chunk: bytes, physical_type: str, type_length: in
         dict_buf, dict_n = bufs[0]["dst"], int(r.out_values)
         col.dictionary = dict_buf.numpy()[: r.out_bytes].copy()
         if byte_array:
-            col.dictionary_offsets = bufs[0]["offsets"].numpy()[: 4 * (dict_n + 1)].view(np.uint32).copy()
+            dict_off = bufs[0]["offsets"]
+            col.dictionary_offsets = dict_off.numpy()[: 4 * (dict_n + 1)].view(np.uint32).copy()
+        if kind == KIND.BOOLEAN:
+            dict_n = 8 * int(r.out_bytes)  # PLAIN booleans are bits: the entry count is the header's (checked by the look-up itself)
     # ---- every level and value part of every data page in one batch ----
     todo = [(it, part) for it, part in zip(items, parts) if part.role != PART_DICT]
     bufs = []
     for it, part in todo:
         bufs.append(room(it, part))
-        if part.role == PART_VALUES and it.encoding == ENC.RLE_DICTIONARY and dict_buf is not None and not byte_array and \
-                kind != KIND.FIXED_LEN_BYTE_ARRAY and kind != KIND.BOOLEAN:
+        if part.role == PART_VALUES and it.encoding == ENC.RLE_DICTIONARY and dict_buf is not None:
             it.dict, it.dict_len = dict_buf.ptr, dict_n  # Dictionary.Lookup fused into the index decode
+            if byte_array:
+                it.dict_offsets = dict_off.ptr
         elif part.role == PART_VALUES and it.encoding == ENC.RLE_DICTIONARY:
             it.kind = KIND.INT32  # the indexes themselves, as indexedPageType.Decode yields them (dictionary.go:217-219)
     res = _run(ctx, [it for it, _ in todo], bufs) if todo else []
@@ -165,13 +171,15 @@ def decode_chunk(ctx: Context, chunk: bytes, physical_type: str, type_length: in
         col.num_values += h.num_values
         if int(r.out_values) < n and kind != KIND.BOOLEAN:
             raise PqdError(STATUS.UNEXPECTED_EOF, r.out_values, f"page {part.page}: {r.out_values} values for {n} slots")
-        if byte_array and it.encoding != ENC.RLE_DICTIONARY:
+        if byte_array and (it.encoding != ENC.RLE_DICTIONARY or it.dict):
             o = b["offsets"].numpy()[: 4 * (n + 1)].view(np.uint32).astype(np.int64)
             vals.append(b["dst"].numpy()[: int(o[-1])].copy())
             offs.append(o[:-1] + base)
             base += int(o[-1])
         elif it.encoding == ENC.RLE_DICTIONARY and not it.dict:
             idx.append(b["dst"].numpy()[: 4 * n].view(np.int32).copy())
+        elif kind == KIND.BOOLEAN and it.dict:
+            vals.append(b["dst"].numpy()[:n].copy())  # looked up in a dictionary: a byte per value
         elif kind == KIND.BOOLEAN:
             vals.append(np.unpackbits(b["dst"].numpy()[: int(r.out_bytes)], bitorder="little")[:n].copy())
         else:

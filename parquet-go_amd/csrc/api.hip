@@ -57,6 +57,7 @@ struct pqd_batch {
     hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
     // generic tile grids for the element-parallel families
     uint64_t max_src[N_FAMILIES] = {0}; // longest src of each family, sizes the tile grids
+    uint64_t dict_bytes_max_values = 0; // most values a page looked up in a byte dictionary may hold
     uint64_t dba_max_values = 0; // most values a DELTA_BYTE_ARRAY page of the batch is expected to hold
     uint64_t flat_blocks[N_FAMILIES] = {0}; // DELTA families decoded tile by tile: most blocks a page may hold (0: not used)
     std::vector<DevResult> h_results;
@@ -135,6 +136,7 @@ int32_t classify(const pqd_page& p) {
                 if (k == PQD_KIND_INT32 || k == PQD_KIND_INT64 || k == PQD_KIND_FLOAT || k == PQD_KIND_DOUBLE ||
                     k == PQD_KIND_INT96)
                     return FAM_RLE;
+                if (k == PQD_KIND_BYTE_ARRAY || k == PQD_KIND_FIXED_LEN_BYTE_ARRAY || k == PQD_KIND_BOOLEAN) return FAM_DICT_BYTES;
                 return FAM_NONE;
             }
             // Without a dictionary the item stands for the codec object's own DecodeInt32:
@@ -174,6 +176,7 @@ DevPage make_item(const pqd_page& p, int32_t family) {
     d.offsets_cap = p.offsets_cap;
     d.dict = static_cast<const uint8_t*>(p.dict);
     d.dict_len = p.dict_len;
+    d.dict_offsets = p.dict_offsets;
     d.num_values = p.num_values;
     d.encoding = p.encoding;
     d.kind = p.kind;
@@ -302,6 +305,37 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
             runs_entries += d.runs_cap;
             m.primary = (int32_t)b->items.size();
             b->items.push_back(d);
+        } else if (family == FAM_DICT_BYTES) {
+            // the indexes are decoded (and cut or zero-extended to num_values) into scratch by an RLE hybrid item;
+            // as many as the caller's buffers could take values
+            const bool ba = p.kind == PQD_KIND_BYTE_ARRAY;
+            const uint64_t width = p.kind == PQD_KIND_BOOLEAN ? 1 : (p.bit_width > 0 ? (uint64_t)p.bit_width : 0);
+            if ((ba && (p.dict_offsets == nullptr || (p.offsets == nullptr && p.offsets_cap > 0))) || (!ba && width == 0)) {
+                m.host_status = PQD_ERR_INVALID_ARGUMENT;
+                m.host_arg = ba ? 0 : (int64_t)p.bit_width;
+            } else {
+                uint64_t cap = ba ? (p.offsets_cap > 0 ? p.offsets_cap - 1 : 0) : p.dst_cap / width;
+                if (p.num_values >= 0) cap = (uint64_t)p.num_values;
+                if (cap > 0x7fffffffull) cap = 0x7fffffffull;
+                DevPage ix = make_item(p, FAM_RLE);
+                ix.kind = PQD_KIND_INT32;
+                ix.elem_width = 4;
+                ix.dict = nullptr; ix.dict_len = 0; ix.fused = 0;
+                ix.dst_stride = 0;
+                ix.dst_cap = cap * 4;
+                // (dst is pointed into the arena after the carve)
+                ix.runs_cap = p.src_len + 1;
+                runs_entries += ix.runs_cap;
+                const int32_t ix_idx = (int32_t)b->items.size();
+                b->items.push_back(ix);
+                DevPage d = make_item(p, family);
+                d.chain = ix_idx;
+                d.lengths_cap = cap;
+                lengths_entries += cap + 8;
+                b->dict_bytes_max_values = std::max<uint64_t>(b->dict_bytes_max_values, cap);
+                m.primary = (int32_t)b->items.size();
+                b->items.push_back(d);
+            }
         } else if (family == FAM_DLBA) {
             // the lengths are decoded straight into the caller's offsets buffer and scanned there
             if (p.offsets == nullptr && p.offsets_cap > 0) {
@@ -606,6 +640,13 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
             d.tile_run = reinterpret_cast<uint32_t*>(a + o_rle_tile_run) + d.lengths_cap;
             d.lengths_cap = 0;
         }
+        if (d.family == FAM_DICT_BYTES) {
+            DevPage& ix = b->items[d.chain];
+            d.lengths = lengths;
+            ix.dst = reinterpret_cast<uint8_t*>(lengths);
+            ix.lengths_cap = 0;
+            lengths += d.lengths_cap + 8;
+        }
         if (d.family == FAM_DBA) {
             // [prefix | suffix], each lengths_cap entries (+4 of slack so that vector stores of the decoder stay inside)
             DevPage& suf = b->items[d.chain];
@@ -700,6 +741,7 @@ int pqd_batch_launch(pqd_batch* b, void* hip_stream) {
     launch_bss(b->d_items, b->d_results, b->fam[FAM_BSS].dev, fam_n(FAM_BSS), b->max_src[FAM_BSS], s_flat);
     launch_plain_fixed(b->d_items, b->d_results, b->fam[FAM_PLAIN_FIXED].dev, fam_n(FAM_PLAIN_FIXED), b->max_src[FAM_PLAIN_FIXED], s_flat);
     launch_plain_byte_array(b->d_items, b->d_results, b->fam[FAM_PLAIN_BYTE_ARRAY].dev, fam_n(FAM_PLAIN_BYTE_ARRAY), s_walk);
+    launch_dict_bytes(b->d_items, b->d_results, b->fam[FAM_DICT_BYTES].dev, fam_n(FAM_DICT_BYTES), b->dict_bytes_max_values, s_rle);
     launch_dlba(b->d_items, b->d_results, b->fam[FAM_DLBA].dev, fam_n(FAM_DLBA), b->max_src[FAM_DLBA], s);
     launch_dba(b->d_items, b->d_results, b->fam[FAM_DBA].dev, fam_n(FAM_DBA), b->dba_max_values, s);
     if (b->side_by_side) {

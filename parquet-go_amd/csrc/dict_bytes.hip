@@ -1,0 +1,238 @@
+// dict_bytes.hip -- Dictionary.Lookup for dictionaries whose values are not 4, 8 or 12 bytes wide:
+// BYTE_ARRAY (byteArrayDictionary, dictionary_byte_array.go; lookupString,
+// dictionary_purego.go:40-45), FIXED_LEN_BYTE_ARRAY of any size (fixedLenByteArrayDictionary,
+// dictionary_purego.go:47-52) and BOOLEAN (booleanDictionary.lookup, dictionary_boolean.go:93-98).
+//
+// The reference hands out string headers that point into the dictionary; a column that stays on
+// the device is materialised instead, in the layout DecodeByteArray produces: the values back to
+// back and n + 1 offsets.  Two kernels per batch (or per call of the stand-alone entry point):
+//   offsets  one workgroup per page: bounds check of every index (the reference panics
+//            "index out of bounds", errors.go:75-83), length of the value it names, exclusive
+//            sum -> offsets; FIXED_LEN_BYTE_ARRAY and BOOLEAN only check.
+//   copy     a wavefront per 64 values: the bytes of value after value, a lane per byte.
+// Fused with RLE_DICTIONARY pages, the indexes come from an RLE hybrid item of the same batch
+// that decodes them (with newIndexedPage's length fix-up) into scratch.
+#include "pqd_internal.h"
+
+namespace pqd {
+namespace {
+
+constexpr int DT = 256;
+
+// What the two kernels work on: a page of a batch, or the arguments of a stand-alone call.
+struct Lookup {
+    gptr<const uint32_t> idx;   // n indexes
+    uint64_t n;
+    gptr<const uint8_t> dict;   // value bytes (BOOLEAN: packed bits, LSB first)
+    gptr<const uint32_t> doff;  // BYTE_ARRAY: dict_len + 1 offsets into dict
+    uint64_t dict_len;
+    uint32_t width;             // FIXED_LEN_BYTE_ARRAY: bytes per value; BOOLEAN: 1
+    int32_t kind;
+    gptr<uint8_t> dst;
+    uint64_t dst_cap;
+    gptr<uint32_t> offsets;     // BYTE_ARRAY: n + 1 offsets out
+    uint64_t offsets_cap;
+};
+
+struct Outcome {
+    int32_t status;
+    int64_t arg;
+    uint64_t out_values, out_bytes;
+};
+
+// Runs in one workgroup of DT threads; the outcome is valid in thread 0.
+__device__ inline Outcome lookup_offsets(const Lookup& L) {
+    __shared__ uint32_t wsum[DT / 64];
+    __shared__ unsigned long long first_bad;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    Outcome o = {PQD_OK, 0, 0, 0};
+    const bool ba = L.kind == PQD_KIND_BYTE_ARRAY;
+    if (ba && L.n + 1 > L.offsets_cap) { o.status = PQD_ERR_OFFSETS_TOO_SMALL; o.arg = (int64_t)(L.n + 1); return o; }
+    if (!ba && (L.width == 0 || L.n > L.dst_cap / L.width)) {
+        o.status = L.width == 0 ? PQD_ERR_INVALID_ARGUMENT : PQD_ERR_DST_TOO_SMALL;
+        o.arg = (int64_t)(L.n * L.width);
+        return o;
+    }
+    if (tid == 0) first_bad = ~0ull;
+    __syncthreads();
+    uint32_t carry = 0;
+    for (uint64_t base = 0; base < L.n; base += (uint64_t)DT * 4) {
+        const uint64_t k = base + tid * 4;
+        uint32_t v[4] = {0, 0, 0, 0};
+        for (uint32_t e = 0; e < 4; e++)
+            if (k + e < L.n) {
+                const uint32_t j = L.idx[k + e];
+                if ((uint64_t)j >= L.dict_len) atomicMin(&first_bad, (unsigned long long)(k + e));
+                else if (ba) v[e] = L.doff[j + 1] - L.doff[j];
+            }
+        if (!ba) continue; // uniform
+        const uint32_t mine = v[0] + v[1] + v[2] + v[3];
+        const uint32_t x = wave_inclusive_scan<uint32_t>(mine);
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        uint32_t before = carry, all = 0;
+        for (uint32_t w = 0; w < DT / 64; w++) {
+            if (w < wave) before += wsum[w];
+            all += wsum[w];
+        }
+        uint32_t at = before + x - mine;
+        for (uint32_t e = 0; e < 4; e++)
+            if (k + e < L.n) { L.offsets[k + e] = at; at += v[e]; }
+        carry += all;
+        __syncthreads();
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (first_bad != ~0ull) { o.status = PQD_ERR_INDEX_OUT_OF_BOUNDS; o.arg = (int64_t)first_bad; }
+        else if (ba) {
+            L.offsets[L.n] = carry;
+            if ((uint64_t)carry > L.dst_cap) { o.status = PQD_ERR_DST_TOO_SMALL; o.arg = (int64_t)carry; o.out_values = L.n; }
+            else { o.out_values = L.n; o.out_bytes = carry; }
+        } else {
+            o.out_values = L.n;
+            o.out_bytes = L.n * L.width;
+        }
+    }
+    return o;
+}
+
+// The values [k0, k0 + 64) of the page by one wavefront.
+__device__ inline void lookup_copy(const Lookup& L, uint64_t k0) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t k = k0 + lane;
+    const bool in = k < L.n;
+    const uint32_t j = in ? L.idx[k] : 0u;
+    if (L.kind == PQD_KIND_BOOLEAN) {
+        if (in) L.dst[k] = (uint8_t)((L.dict[j >> 3] >> (j & 7)) & 1);
+        return;
+    }
+    const bool ba = L.kind == PQD_KIND_BYTE_ARRAY;
+    uint64_t from = 0, to = 0;
+    uint32_t len = 0;
+    if (in) {
+        if (ba) { from = L.doff[j]; len = L.doff[j + 1] - L.doff[j]; to = L.offsets[k]; }
+        else { from = (uint64_t)j * L.width; len = L.width; to = k * L.width; }
+    }
+    const uint32_t cnt = L.n - k0 < 64 ? (uint32_t)(L.n - k0) : 64u;
+    for (uint32_t v = 0; v < cnt; v++) {
+        const uint32_t n = lane_u32(len, v);
+        gptr<const uint8_t> s = L.dict + lane_u64(from, v);
+        gptr<uint8_t> d = L.dst + lane_u64(to, v);
+        for (uint32_t b = lane; b < n; b += 64) d[b] = s[b];
+    }
+}
+
+// ---- pages of a batch ----
+
+__device__ inline Lookup lookup_of(const DevPage& pg, const DevResult& lr) {
+    Lookup L;
+    L.idx = (gptr<const uint32_t>)as_global(pg.lengths);
+    L.n = lr.out_values;
+    L.dict = as_global(pg.dict);
+    L.doff = as_global(pg.dict_offsets);
+    L.dict_len = pg.dict_len;
+    L.width = pg.kind == PQD_KIND_BOOLEAN ? 1u : (uint32_t)(pg.bit_width > 0 ? pg.bit_width : 0);
+    L.kind = pg.kind;
+    L.dst = as_global(pg.dst);
+    L.dst_cap = pg.dst_cap;
+    L.offsets = as_global(pg.offsets);
+    L.offsets_cap = pg.offsets_cap;
+    return L;
+}
+
+__global__ __launch_bounds__(DT) void dict_bytes_offsets_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                                const uint32_t* __restrict__ items) {
+    const uint32_t item = items[blockIdx.x];
+    const DevPage& pg = pages[item];
+    DevResult* res = &results[item];
+    const DevResult lr = results[pg.chain]; // the item that decoded the indexes
+    if (lr.status != PQD_OK) {
+        if (threadIdx.x == 0) {
+            int32_t st = lr.status;
+            int64_t arg = lr.arg;
+            if (st == PQD_ERR_DST_TOO_SMALL) { // more indexes than the caller's buffers were sized for
+                const uint64_t total = (uint64_t)lr.arg / 4;
+                if (pg.kind == PQD_KIND_BYTE_ARRAY) { st = PQD_ERR_OFFSETS_TOO_SMALL; arg = (int64_t)(total + 1); }
+                else arg = (int64_t)(total * (uint64_t)(pg.kind == PQD_KIND_BOOLEAN ? 1 : (pg.bit_width > 0 ? pg.bit_width : 1)));
+            }
+            res->status = st; res->arg = arg; res->out_values = 0; res->out_bytes = 0; res->consumed = lr.consumed; res->total = 0;
+        }
+        return;
+    }
+    const Outcome o = lookup_offsets(lookup_of(pg, lr));
+    if (threadIdx.x == 0) {
+        res->status = o.status; res->arg = o.arg; res->out_values = o.out_values; res->out_bytes = o.out_bytes;
+        res->consumed = lr.consumed; res->total = lr.out_values;
+    }
+}
+
+__global__ __launch_bounds__(DT) void dict_bytes_copy_kernel(const DevPage* __restrict__ pages, const DevResult* __restrict__ results,
+                                                             const uint32_t* __restrict__ items) {
+    const uint32_t item = items[blockIdx.x];
+    const DevPage& pg = pages[item];
+    if (results[item].status != PQD_OK) return;
+    const Lookup L = lookup_of(pg, results[pg.chain]);
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint64_t k0 = ((uint64_t)blockIdx.y * (DT / 64) + wave) * 64; k0 < L.n; k0 += (uint64_t)gridDim.y * DT) lookup_copy(L, k0);
+}
+
+// ---- a stand-alone call ----
+
+__global__ __launch_bounds__(DT) void dict_bytes_call_offsets_kernel(Lookup L, int64_t* __restrict__ status) {
+    const Outcome o = lookup_offsets(L);
+    if (threadIdx.x == 0) { status[0] = o.status; status[1] = o.arg; status[2] = (int64_t)o.out_bytes; }
+}
+
+__global__ __launch_bounds__(DT) void dict_bytes_call_copy_kernel(Lookup L, const int64_t* __restrict__ status) {
+    if (status[0] != PQD_OK) return;
+    const uint32_t wave = threadIdx.x >> 6;
+    for (uint64_t k0 = ((uint64_t)blockIdx.x * (DT / 64) + wave) * 64; k0 < L.n; k0 += (uint64_t)gridDim.x * DT) lookup_copy(L, k0);
+}
+
+uint32_t copy_groups(uint64_t n) {
+    const uint64_t g = (n + DT - 1) / DT;
+    return (uint32_t)(g < 1 ? 1 : (g > 16384 ? 16384 : g));
+}
+
+} // namespace
+
+void launch_dict_bytes(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_values,
+                       hipStream_t stream) {
+    if (n_items == 0) return;
+    hipLaunchKernelGGL(dict_bytes_offsets_kernel, dim3(n_items), dim3(DT), 0, stream, pages, results, items);
+    hipLaunchKernelGGL(dict_bytes_copy_kernel, dim3(n_items, copy_groups(max_values)), dim3(DT), 0, stream, pages, results, items);
+}
+
+} // namespace pqd
+
+using namespace pqd;
+
+extern "C" int pqd_dict_lookup_bytes_device(pqd_ctx* ctx, int32_t kind, const void* dict_dev, const uint32_t* dict_offsets_dev,
+                                            uint64_t dict_len, uint32_t width, const int32_t* indexes_dev, uint64_t n, void* dst_dev,
+                                            uint64_t dst_cap, uint32_t* offsets_dev, uint64_t offsets_cap, int64_t* status_dev,
+                                            void* hip_stream) {
+    if (ctx == nullptr || status_dev == nullptr || (indexes_dev == nullptr && n > 0) || (dst_dev == nullptr && dst_cap > 0) ||
+        (dict_dev == nullptr && dict_len > 0))
+        return PQD_ERR_INVALID_ARGUMENT;
+    if (kind != PQD_KIND_BYTE_ARRAY && kind != PQD_KIND_FIXED_LEN_BYTE_ARRAY && kind != PQD_KIND_BOOLEAN) return PQD_ERR_NOT_SUPPORTED;
+    if (kind == PQD_KIND_BYTE_ARRAY && (dict_offsets_dev == nullptr || offsets_dev == nullptr)) return PQD_ERR_INVALID_ARGUMENT;
+    if (kind == PQD_KIND_FIXED_LEN_BYTE_ARRAY && width == 0) return PQD_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return PQD_ERR_DEVICE;
+    Lookup L; // (plain casts: on the host a pointer is a number to hand on)
+    L.idx = (gptr<const uint32_t>)reinterpret_cast<const uint32_t*>(indexes_dev);
+    L.n = n;
+    L.dict = (gptr<const uint8_t>)static_cast<const uint8_t*>(dict_dev);
+    L.doff = (gptr<const uint32_t>)dict_offsets_dev;
+    L.dict_len = dict_len;
+    L.width = kind == PQD_KIND_BOOLEAN ? 1u : width;
+    L.kind = kind;
+    L.dst = (gptr<uint8_t>)static_cast<uint8_t*>(dst_dev);
+    L.dst_cap = dst_cap;
+    L.offsets = (gptr<uint32_t>)offsets_dev;
+    L.offsets_cap = offsets_cap;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    hipLaunchKernelGGL(dict_bytes_call_offsets_kernel, dim3(1), dim3(DT), 0, s, L, status_dev);
+    hipLaunchKernelGGL(dict_bytes_call_copy_kernel, dim3(copy_groups(n)), dim3(DT), 0, s, L, status_dev);
+    return hipGetLastError() == hipSuccess ? PQD_OK : PQD_ERR_DEVICE;
+}

@@ -63,6 +63,7 @@ struct DevPage {
     uint64_t offsets_cap;
     const uint8_t* dict;
     uint64_t dict_len;
+    const uint32_t* dict_offsets;
     int64_t num_values;
     int32_t encoding;
     int32_t kind;
@@ -128,6 +129,7 @@ enum Family : int32_t {
     FAM_RLE_DICT4 = 14, // ... of 4-byte values
     FAM_RLE_LDS8 = 15,  // RLE hybrid through a dictionary of 8-byte values held in LDS, dense destination
     FAM_RLE_LDS4 = 16,  // ... of 4-byte values
+    FAM_DICT_BYTES = 17, // look-up in a BYTE_ARRAY / FIXED_LEN_BYTE_ARRAY / BOOLEAN dictionary of indexes an RLE item decoded
     N_FAMILIES = 20
 };
 
@@ -250,6 +252,8 @@ void launch_dlba(const DevPage* pages, DevResult* results, const uint32_t* items
                  hipStream_t stream);
 void launch_dba(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_values,
                 hipStream_t stream);
+void launch_dict_bytes(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_values,
+                       hipStream_t stream);
 void launch_sum_lengths(const int32_t* v, uint64_t n, uint32_t* out, hipStream_t stream);
 
 int levels_scratch_address(void** out); // device address of the static workspace, for the current device

@@ -101,7 +101,9 @@ class PageSpec:
     num_values: int = -1
     dst_cap: int = 0              # bytes; 0 = let decode_pages pick a generous bound
     offsets_cap: int = 0          # entries
-    dictionary: Optional[np.ndarray] = None  # fixed-width dictionary values
+    dictionary: Optional[np.ndarray] = None  # dictionary values (fixed width; bytes of a BYTE_ARRAY dictionary; packed bits of a BOOLEAN one)
+    dictionary_offsets: Optional[np.ndarray] = None  # BYTE_ARRAY dictionary: entries + 1 uint32 offsets
+    dictionary_len: int = -1      # entries, when len(dictionary) does not say (byte and bit dictionaries)
     dst_stride: int = 0
     misalign: int = 0             # byte misalignment of src in device memory
 
@@ -142,6 +144,12 @@ def decode_pages(ctx: Context, specs: List[PageSpec], device: int = 0, grow: boo
         p.dict, p.dict_len = (d.ptr if d is not None else None), (len(s.dictionary) if s.dictionary is not None else 0)
         if d is not None and p.dict_len == 0:
             p.dict = d.ptr
+        if s.dictionary_len >= 0:
+            p.dict_len = s.dictionary_len
+        if s.dictionary_offsets is not None:
+            do = to_device(np.ascontiguousarray(s.dictionary_offsets, dtype=np.uint32), device)
+            dicts.append(do)
+            p.dict_offsets, p.dict_len = do.ptr, len(s.dictionary_offsets) - 1
         p.num_values = s.num_values
         p.encoding, p.kind, p.bit_width, p.dst_stride = s.encoding, s.kind, s.bit_width, s.dst_stride
         srcs.append(src); dsts.append(dst); offs.append(off); dicts.append(d); pages.append(p)

@@ -33,7 +33,7 @@ def test_header_symbols_are_exported():
 def test_abi_version_and_status_names():
     pkg = entry.load_package()
     L = pkg.lib()
-    assert L.pqd_abi_version() == 1
+    assert L.pqd_abi_version() == 2
     assert L.pqd_status_name(0) == b"OK"
     assert L.pqd_status_name(9) == b"MISSING_VALUES"
     assert L.pqd_status_name(19) == b"CHECKSUM"
@@ -43,8 +43,8 @@ def test_abi_version_and_status_names():
 
 def test_page_struct_layout_matches_header():
     pkg = entry.load_package()
-    # 9 x 8-byte fields, 4 x int32, 2 x int32, int64, 3 x uint64
-    assert ctypes.sizeof(pkg.Page) == 9 * 8 + 4 * 4 + 2 * 4 + 8 + 3 * 8
+    # 10 x 8-byte fields, 4 x int32, 2 x int32, int64, 3 x uint64
+    assert ctypes.sizeof(pkg.Page) == 10 * 8 + 4 * 4 + 2 * 4 + 8 + 3 * 8
 
 
 def test_no_gpu_fails_loudly():
