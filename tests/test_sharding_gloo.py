@@ -49,6 +49,12 @@ def _worker(rank, world, port, out_dir):
         work["steps"] += 1
         time.sleep(0.01 if rank == 0 else 0.03)
 
+    # the page-dealing code of `bench.py --config wide`: this rank's column chunks of a 6 x 7 table
+    import bench_wide as W
+    cells = W.cells_of(rank, world, 6, 7)
+    with open(os.path.join(out_dir, f"cells{rank}.txt"), "w") as f:
+        f.write("\n".join(f"{g} {c} {name}" for g, c, name in cells))
+
     wall = S.timed_region(step, steps=5, warmup=2, sync=lambda: None, barrier=dist.barrier)
     slowest = S.max_over_ranks(wall, dist)
     rate = S.whole_job_rate(len(mine), world, slowest / 5)
@@ -65,6 +71,13 @@ def test_two_ranks_gloo(tmp_path):
     port = s.getsockname()[1]
     s.close()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    # the ranks' shares of the wide table are disjoint and together are the table
+    import bench_wide as W
+    shares = [[tuple(line.split()) for line in open(tmp_path / f"cells{r}.txt").read().splitlines()] for r in range(2)]
+    assert not set(shares[0]) & set(shares[1])
+    table = [(str(g), str(c), name) for g, c, name in W.table_cells(6, 7)]
+    assert sorted(shares[0] + shares[1]) == sorted(table) and len(table) == 42
+    assert all(int(g) % 2 == r for r in range(2) for g, _, _ in shares[r])
     rows = [open(tmp_path / f"r{r}.txt").read().split() for r in range(2)]
     for r in rows:
         assert int(r[0]) == 7           # 2 warm-up + exactly 5 timed steps
