@@ -38,6 +38,7 @@ struct pqd_batch {
     std::vector<DevPage> items;
     void* arena = nullptr;
     size_t arena_bytes = 0;
+    bool own_arena = true; // false: the arena belongs to a caller's workspace
     DevPage* d_items = nullptr;
     DevResult* d_results = nullptr;
     FamilyList fam[N_FAMILIES];
@@ -62,7 +63,7 @@ struct pqd_batch {
     uint64_t flat_blocks[N_FAMILIES] = {0}; // DELTA families decoded tile by tile: most blocks a page may hold (0: not used)
     std::vector<DevResult> h_results;
     ~pqd_batch() {
-        if (arena) (void)hipFree(arena);
+        if (arena && own_arena) (void)hipFree(arena);
         if (fork) (void)hipEventDestroy(fork);
         for (hipEvent_t e : join)
             if (e) (void)hipEventDestroy(e);
@@ -72,12 +73,6 @@ struct pqd_batch {
 namespace {
 
 inline bool hip_ok(hipError_t e) { return e == hipSuccess; }
-
-#define PQD_HIP(call)                                   \
-    do {                                                \
-        hipError_t e_ = (call);                         \
-        if (e_ != hipSuccess) return PQD_ERR_DEVICE;    \
-    } while (0)
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -192,6 +187,26 @@ DevPage make_item(const pqd_page& p, int32_t family) {
 
 } // namespace
 
+Workspace* pqd::workspace_acquire(pqd_ctx* ctx) {
+    {
+        std::lock_guard<std::mutex> lock(ctx->mu);
+        if (!ctx->idle.empty()) {
+            Workspace* ws = ctx->idle.back();
+            ctx->idle.pop_back();
+            return ws;
+        }
+    }
+    Workspace* ws = new (std::nothrow) Workspace;
+    if (ws == nullptr) return nullptr;
+    if (hipStreamCreateWithFlags(&ws->stream, hipStreamNonBlocking) != hipSuccess) { delete ws; return nullptr; }
+    return ws;
+}
+
+void pqd::workspace_release(pqd_ctx* ctx, Workspace* ws) {
+    std::lock_guard<std::mutex> lock(ctx->mu);
+    ctx->idle.push_back(ws);
+}
+
 extern "C" {
 
 int pqd_abi_version(void) { return PQD_ABI_VERSION; }
@@ -264,12 +279,21 @@ int pqd_ctx_create(int device, pqd_ctx** out) {
 void pqd_ctx_destroy(pqd_ctx* ctx) {
     if (ctx == nullptr) return;
     DeviceGuard guard(ctx->device);
+    for (Workspace* ws : ctx->idle) { ws->release(); delete ws; }
     for (hipStream_t st : ctx->side)
         if (st != nullptr) (void)hipStreamDestroy(st);
     delete ctx;
 }
 
 int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_batch** out) {
+    return pqd::batch_create_ws(ctx, pages, n_pages, out, nullptr);
+}
+
+} // extern "C"
+
+// pqd_batch_create; with a workspace, the arena and the host image of its uploaded part are the
+// workspace's (kept from call to call) and the upload is one asynchronous copy on its stream.
+int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_batch** out, Workspace* ws) {
     if (ctx == nullptr || out == nullptr || (pages == nullptr && n_pages > 0)) return PQD_ERR_INVALID_ARGUMENT;
     *out = nullptr;
     DeviceGuard guard(ctx->device);
@@ -568,12 +592,13 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
         o_lds_wg[g] = carve(lds_wg[g].size() * sizeof(uint32_t));
         o_lds_seg[g] = carve(lds_seg[g].size() * sizeof(uint32_t));
     }
-    const size_t o_rle_tile_run = carve(b->rle_steps * sizeof(uint32_t));
     const size_t nck = b->ck.n_chunks, npk = ck_items.size();
     const size_t o_ck_items = carve(npk * sizeof(uint32_t));
     const size_t o_ck_prefix = carve(ck_prefix.size() * sizeof(uint32_t));
     const size_t o_ck_page = carve(nck * sizeof(uint32_t));
     const size_t o_ck_chunk = carve(nck * sizeof(uint32_t));
+    const size_t upload_end = off; // everything up to here comes from the host; the rest is scratch
+    const size_t o_rle_tile_run = carve(b->rle_steps * sizeof(uint32_t));
     const size_t o_ck_entry = carve(nck * sizeof(uint32_t));
     const size_t o_ck_exit = carve(nck * sizeof(uint32_t));
     const size_t o_ck_links = carve(nck * (size_t)rle_chunk_bytes() * sizeof(uint16_t));
@@ -603,7 +628,11 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
     }
     const size_t o_flat = carve(flat_bytes);
     b->arena_bytes = std::max<size_t>(off, 256);
-    if (hipMalloc(&b->arena, b->arena_bytes) != hipSuccess) { delete b; return PQD_ERR_DEVICE; }
+    if (ws != nullptr) {
+        if (!ws->reserve_arena(b->arena_bytes)) { delete b; return PQD_ERR_DEVICE; }
+        b->arena = ws->arena;
+        b->own_arena = false;
+    } else if (hipMalloc(&b->arena, b->arena_bytes) != hipSuccess) { delete b; return PQD_ERR_DEVICE; }
     uint8_t* a = static_cast<uint8_t*>(b->arena);
     b->d_items = reinterpret_cast<DevPage*>(a + o_items);
     b->d_results = reinterpret_cast<DevResult*>(a + o_results);
@@ -660,45 +689,49 @@ int pqd_batch_create(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_
         }
     }
 
-    // ---- upload ----
-    bool ok = true;
-    if (n_items) ok = ok && hip_ok(hipMemcpy(b->d_items, b->items.data(), n_items * sizeof(DevPage), hipMemcpyHostToDevice));
-    ok = ok && hip_ok(hipMemset(b->d_results, 0, std::max<size_t>(1, n_items) * sizeof(DevResult)));
+    // ---- upload: a host image of the arena's front part, copied in one go ----
+    std::vector<uint8_t> local;
+    uint8_t* image;
+    if (ws != nullptr) {
+        if (!ws->reserve_pinned(upload_end + n_items * sizeof(DevResult))) { delete b; return PQD_ERR_DEVICE; }
+        image = static_cast<uint8_t*>(ws->pinned);
+        std::memset(image, 0, upload_end);
+    } else {
+        local.assign(upload_end, 0);
+        image = local.data();
+    }
+    auto put = [&](size_t at, const void* p, size_t n) { if (n) std::memcpy(image + at, p, n); };
+    put(o_items, b->items.data(), n_items * sizeof(DevPage)); // (the results behind them start out as zeros)
     for (int f = 0; f < N_FAMILIES; f++) {
         b->fam[f].dev = reinterpret_cast<uint32_t*>(a + o_fam[f]);
-        if (!b->fam[f].items.empty())
-            ok = ok && hip_ok(hipMemcpy(b->fam[f].dev, b->fam[f].items.data(), b->fam[f].items.size() * sizeof(uint32_t),
-                                        hipMemcpyHostToDevice));
+        put(o_fam[f], b->fam[f].items.data(), b->fam[f].items.size() * sizeof(uint32_t));
     }
     for (int g = 0; g < RLE_GRIDS; g++) {
-        ok = ok && hip_ok(hipMemcpy(b->d_rle_tile_prefix[g], rle_prefix[g].data(), rle_prefix[g].size() * sizeof(uint64_t),
-                                    hipMemcpyHostToDevice));
+        put(o_rle_prefix[g], rle_prefix[g].data(), rle_prefix[g].size() * sizeof(uint64_t));
         if (with_tile_item[g] && b->rle_tiles[g] > 0) {
-            std::vector<uint32_t> tile_item(b->rle_tiles[g]);
+            uint32_t* tile_item = reinterpret_cast<uint32_t*>(image + o_rle_tile_item[g]);
             for (size_t k = 0; k + 1 < rle_prefix[g].size(); k++)
-                std::fill(tile_item.begin() + rle_prefix[g][k], tile_item.begin() + rle_prefix[g][k + 1], (uint32_t)k);
-            ok = ok && hip_ok(hipMemcpy(b->d_rle_tile_item[g], tile_item.data(), tile_item.size() * sizeof(uint32_t),
-                                        hipMemcpyHostToDevice));
+                std::fill(tile_item + rle_prefix[g][k], tile_item + rle_prefix[g][k + 1], (uint32_t)k);
         }
-    }
-    for (int g = 0; g < RLE_GRIDS; g++) {
         if (lds_wg[g].empty()) continue;
         b->d_lds_wg_item[g] = reinterpret_cast<uint32_t*>(a + o_lds_wg[g]);
         b->d_lds_seg_last[g] = reinterpret_cast<uint32_t*>(a + o_lds_seg[g]);
-        ok = ok && hip_ok(hipMemcpy(b->d_lds_wg_item[g], lds_wg[g].data(), lds_wg[g].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        ok = ok && hip_ok(hipMemcpy(b->d_lds_seg_last[g], lds_seg[g].data(), lds_seg[g].size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        put(o_lds_wg[g], lds_wg[g].data(), lds_wg[g].size() * sizeof(uint32_t));
+        put(o_lds_seg[g], lds_seg[g].data(), lds_seg[g].size() * sizeof(uint32_t));
     }
-    if (nck > 0) {
-        ok = ok && hip_ok(hipMemcpy(a + o_ck_items, ck_items.data(), npk * sizeof(uint32_t), hipMemcpyHostToDevice));
-        ok = ok && hip_ok(hipMemcpy(a + o_ck_prefix, ck_prefix.data(), ck_prefix.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-        ok = ok && hip_ok(hipMemcpy(a + o_ck_page, ck_page.data(), nck * sizeof(uint32_t), hipMemcpyHostToDevice));
-        ok = ok && hip_ok(hipMemcpy(a + o_ck_chunk, ck_chunk.data(), nck * sizeof(uint32_t), hipMemcpyHostToDevice));
-    }
+    put(o_ck_items, ck_items.data(), npk * sizeof(uint32_t));
+    put(o_ck_prefix, ck_prefix.data(), ck_prefix.size() * sizeof(uint32_t));
+    put(o_ck_page, ck_page.data(), nck * sizeof(uint32_t));
+    put(o_ck_chunk, ck_chunk.data(), nck * sizeof(uint32_t));
+    bool ok = ws != nullptr ? hip_ok(hipMemcpyAsync(a, image, upload_end, hipMemcpyHostToDevice, ws->stream))
+                            : hip_ok(hipMemcpy(a, image, upload_end, hipMemcpyHostToDevice));
     if (!ok) { delete b; return PQD_ERR_DEVICE; }
     b->h_results.resize(n_items);
     *out = b;
     return PQD_OK;
 }
+
+extern "C" {
 
 int pqd_batch_launch(pqd_batch* b, void* hip_stream) {
     if (b == nullptr) return PQD_ERR_INVALID_ARGUMENT;
@@ -761,7 +794,26 @@ int pqd_batch_finish(pqd_batch* b, void* hip_stream, pqd_page* pages, uint64_t n
     PQD_HIP(hipStreamSynchronize(s));
     if (!b->items.empty())
         PQD_HIP(hipMemcpy(b->h_results.data(), b->d_results, b->items.size() * sizeof(DevResult), hipMemcpyDeviceToHost));
-    for (uint64_t i = 0; i < n_pages; i++) {
+    pqd::batch_report(b, b->h_results.data(), pages);
+    return PQD_OK;
+}
+
+} // extern "C"
+
+// pqd_batch_finish on a workspace: the results come back by an asynchronous copy into the
+// workspace's pinned memory, one synchronisation in all.
+int pqd::batch_finish_ws(pqd_batch* b, Workspace* ws, pqd_page* pages) {
+    const size_t bytes = b->items.size() * sizeof(DevResult);
+    if (!ws->reserve_pinned(bytes + 64)) return PQD_ERR_DEVICE;
+    if (bytes) PQD_HIP(hipMemcpyAsync(ws->pinned, b->d_results, bytes, hipMemcpyDeviceToHost, ws->stream));
+    PQD_HIP(hipStreamSynchronize(ws->stream));
+    batch_report(b, static_cast<const DevResult*>(ws->pinned), pages);
+    return PQD_OK;
+}
+
+// The result fields of the caller's pages out of the items' device results.
+void pqd::batch_report(pqd_batch* b, const DevResult* results, pqd_page* pages) {
+    for (uint64_t i = 0; i < b->n_pages; i++) {
         const PageMap& m = b->map[i];
         pqd_page& p = pages[i];
         p.reserved = 0;
@@ -771,7 +823,7 @@ int pqd_batch_finish(pqd_batch* b, void* hip_stream, pqd_page* pages, uint64_t n
             p.out_values = p.out_bytes = p.consumed = 0;
             continue;
         }
-        const DevResult& r = b->h_results[m.primary];
+        const DevResult& r = results[m.primary];
         const DevPage& d = b->items[m.primary];
         p.status = r.status;
         p.status_arg = r.arg;
@@ -792,8 +844,9 @@ int pqd_batch_finish(pqd_batch* b, void* hip_stream, pqd_page* pages, uint64_t n
             p.status_arg = (int64_t)r.aux;
         }
     }
-    return PQD_OK;
 }
+
+extern "C" {
 
 void pqd_batch_destroy(pqd_batch* b) {
     if (b == nullptr) return;

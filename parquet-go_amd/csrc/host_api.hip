@@ -5,9 +5,9 @@
 // back; there is no CPU decode path.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <new>
-#include <vector>
 
 #include "pqd_internal.h"
 
@@ -69,13 +69,21 @@ int launch_dict_gather(const void* dict, uint64_t dict_len, uint32_t width, cons
 
 namespace {
 
-struct DevMem {
-    void* p = nullptr;
-    ~DevMem() { if (p) (void)hipFree(p); }
-    bool alloc(size_t n) { return hipMalloc(&p, n ? n : 16) == hipSuccess; }
+// A workspace of the context for the length of one host call.
+struct Lease {
+    pqd_ctx* ctx;
+    Workspace* ws;
+    explicit Lease(pqd_ctx* c) : ctx(c), ws(workspace_acquire(c)) {}
+    ~Lease() { if (ws) workspace_release(ctx, ws); }
+    Lease(const Lease&) = delete;
+    Lease& operator=(const Lease&) = delete;
 };
 
-// One page, host pointers in and out, through the batched device path.
+inline size_t pad256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+// One page, host pointers in and out, through the batched device path.  Staging memory, the
+// batch's arena and the stream are the leased workspace's: a call allocates nothing once the
+// workspace has seen a page of this size, and calls of different threads run on different streams.
 int decode_host(pqd_ctx* ctx, int encoding, int kind, int bit_width, const uint8_t* src, uint64_t src_len, void* dst,
                 uint64_t dst_cap, uint32_t* offsets, uint64_t offsets_cap, uint64_t* out_bytes, uint64_t* out_offsets,
                 int64_t* status_arg) {
@@ -85,30 +93,140 @@ int decode_host(pqd_ctx* ctx, int encoding, int kind, int bit_width, const uint8
     if (ctx == nullptr || (src == nullptr && src_len > 0) || (dst == nullptr && dst_cap > 0)) return PQD_ERR_INVALID_ARGUMENT;
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return PQD_ERR_DEVICE;
-    DevMem dsrc, ddst, doff;
-    // 16 spare bytes so the kernels' aligned 16-byte loads of the last bytes stay inside the allocation
-    if (!dsrc.alloc(src_len + 32) || !ddst.alloc(dst_cap + 32) || !doff.alloc(offsets_cap * 4 + 32)) return PQD_ERR_DEVICE;
-    if (src_len && hipMemcpy(dsrc.p, src, src_len, hipMemcpyHostToDevice) != hipSuccess) return PQD_ERR_DEVICE;
+    Lease lease(ctx);
+    Workspace* ws = lease.ws;
+    if (ws == nullptr) return PQD_ERR_DEVICE;
+    // 32 spare bytes each so the kernels' aligned 16-byte loads of the last bytes stay inside the allocation
+    const size_t o_src = 0, o_dst = pad256(src_len + 32), o_off = o_dst + pad256(dst_cap + 32);
+    const size_t total = o_off + pad256(offsets_cap * 4 + 32);
+    if (!ws->reserve_io(total)) return PQD_ERR_DEVICE;
+    uint8_t* d_io = static_cast<uint8_t*>(ws->d_io);
+    uint8_t* h_io = static_cast<uint8_t*>(ws->h_io);
+    if (src_len) {
+        std::memcpy(h_io + o_src, src, src_len);
+        PQD_HIP(hipMemcpyAsync(d_io + o_src, h_io + o_src, src_len, hipMemcpyHostToDevice, ws->stream));
+    }
     pqd_page p;
     std::memset(&p, 0, sizeof p);
-    p.src = dsrc.p; p.src_len = src_len;
-    p.dst = ddst.p; p.dst_cap = dst_cap;
-    p.offsets = static_cast<uint32_t*>(doff.p); p.offsets_cap = offsets_cap;
+    p.src = d_io + o_src; p.src_len = src_len;
+    p.dst = d_io + o_dst; p.dst_cap = dst_cap;
+    p.offsets = reinterpret_cast<uint32_t*>(d_io + o_off); p.offsets_cap = offsets_cap;
     p.num_values = -1;
     p.encoding = encoding; p.kind = kind; p.bit_width = bit_width;
-    int rc = pqd_decode_batch(ctx, &p, 1, nullptr);
+    pqd_batch* b = nullptr;
+    int rc = batch_create_ws(ctx, &p, 1, &b, ws);
+    if (rc != PQD_OK) return rc;
+    rc = pqd_batch_launch(b, ws->stream);
+    // Most pages fill the destination the caller sized for them: the values start back together with
+    // the results, and only a page that came out shorter or failed is looked at again.
+    const bool with_offsets = offsets != nullptr && kind == PQD_KIND_BYTE_ARRAY;
+    if (rc == PQD_OK && dst_cap)
+        rc = hipMemcpyAsync(h_io + o_dst, d_io + o_dst, dst_cap, hipMemcpyDeviceToHost, ws->stream) == hipSuccess ? PQD_OK : PQD_ERR_DEVICE;
+    if (rc == PQD_OK && with_offsets && offsets_cap)
+        rc = hipMemcpyAsync(h_io + o_off, d_io + o_off, offsets_cap * 4, hipMemcpyDeviceToHost, ws->stream) == hipSuccess ? PQD_OK : PQD_ERR_DEVICE;
+    if (rc == PQD_OK) rc = batch_finish_ws(b, ws, &p);
+    else (void)hipStreamSynchronize(ws->stream);
+    pqd_batch_destroy(b);
     if (rc != PQD_OK) return rc;
     if (status_arg) *status_arg = p.status_arg;
-    uint64_t nb = p.out_bytes < dst_cap ? p.out_bytes : dst_cap;
-    if (nb && hipMemcpy(dst, ddst.p, nb, hipMemcpyDeviceToHost) != hipSuccess) return PQD_ERR_DEVICE;
+    const uint64_t nb = p.out_bytes < dst_cap ? p.out_bytes : dst_cap;
+    if (nb) std::memcpy(dst, h_io + o_dst, nb);
     if (out_bytes) *out_bytes = nb;
-    if (offsets != nullptr && kind == PQD_KIND_BYTE_ARRAY) {
+    if (with_offsets) {
         uint64_t no = p.status == PQD_OK ? p.out_values + 1 : p.out_values;
         if (no > offsets_cap) no = offsets_cap;
-        if (no && hipMemcpy(offsets, doff.p, no * 4, hipMemcpyDeviceToHost) != hipSuccess) return PQD_ERR_DEVICE;
+        if (no) std::memcpy(offsets, h_io + o_off, no * 4);
         if (out_offsets) *out_offsets = no;
     }
     return p.status;
+}
+
+// ---- EstimateDecodeByteArraySize on the host: a walk over the DELTA_BINARY_PACKED framing ----
+struct Reader {
+    const uint8_t* p;
+    const uint8_t* end;
+    bool uvarint(uint64_t* v) {
+        uint64_t x = 0;
+        for (int shift = 0; shift < 70 && p < end; shift += 7) {
+            const uint8_t c = *p++;
+            if (shift == 63 && c > 1) return false;
+            x |= (uint64_t)(c & 0x7f) << shift;
+            if (!(c & 0x80)) { *v = x; return true; }
+        }
+        return false;
+    }
+    bool svarint(int64_t* v) {
+        uint64_t u;
+        if (!uvarint(&u)) return false;
+        *v = (int64_t)(u >> 1) ^ -(int64_t)(u & 1);
+        return true;
+    }
+};
+
+// The wrapping int32 sum of what int32Buffer.decode leaves in its buffer for one
+// DELTA_BINARY_PACKED int32 stream (encoding/delta/delta.go:22-33), and how far the decoder
+// got.  The walk follows decodeInt32 (encoding/delta/binary_packed.go:279-344) step by step,
+// including what it leaves behind when it stops early, because the estimate's callers ignore the
+// error and sum the buffer (length_byte_array.go:65-70, byte_array.go:176-183): the buffer has
+// the header's count of values once the header is accepted, values never reached are zero,
+// a block cut short by a bad width keeps its unpacked deltas without the running sum, and
+// packed data that ends early reads as zeros.
+uint32_t sum_delta_int32(const uint8_t* src, uint64_t len, uint64_t* consumed) {
+    Reader r{src, src + len};
+    *consumed = 0;
+    uint64_t u[3];
+    int64_t first;
+    if (!r.uvarint(&u[0]) || !r.uvarint(&u[1]) || !r.uvarint(&u[2]) || !r.svarint(&first)) return 0;
+    *consumed = (uint64_t)(r.p - src);
+    const int64_t block_size = (int64_t)u[0], n_mini = (int64_t)u[1], total = (int64_t)u[2];
+    if (n_mini <= 0 || block_size <= 0 || block_size % 128 != 0 || block_size > 65536) return 0;
+    if ((block_size / n_mini) % 32 != 0 || total <= 0 || total > INT32_MAX) return 0;
+    if (first < INT32_MIN || first > INT32_MAX) return 0;
+    const uint64_t mini = (uint64_t)(block_size / n_mini);
+    uint32_t last = (uint32_t)first, sum = (uint32_t)first;
+    uint64_t left = (uint64_t)total - 1;
+    while (left > 0 && r.p < r.end) {
+        *consumed = (uint64_t)(r.p - src);
+        int64_t min_delta;
+        if (!r.svarint(&min_delta)) return sum;
+        const uint64_t n_widths = std::min<uint64_t>((uint64_t)n_mini, (uint64_t)(r.end - r.p));
+        const uint8_t* widths = r.p;
+        r.p += n_widths;
+        uint32_t raw = 0, run = last, summed = 0; // this block: deltas as unpacked; running value; values
+        for (uint64_t m = 0; m < n_widths; m++) {
+            const uint32_t w = widths[m];
+            const uint64_t n = std::min(mini, left);
+            if (w != 0) {
+                if (w > 32 && n > 0) { *consumed = (uint64_t)(r.p - src); return sum + raw; }
+                const uint64_t bytes = mini * w / 8;
+                const uint64_t have = std::min<uint64_t>(bytes, (uint64_t)(r.end - r.p));
+                const uint8_t* q = r.p;
+                const uint8_t* q_end = r.p + have;
+                const uint64_t mask = w >= 32 ? 0xffffffffull : ((1ull << w) - 1);
+                uint64_t acc = 0;
+                uint32_t bits = 0;
+                for (uint64_t i = 0; i < n; i++) {
+                    while (bits < w) { acc |= (uint64_t)(q < q_end ? *q : 0) << bits; q++; bits += 8; }
+                    const uint32_t d = (uint32_t)(acc & mask);
+                    acc >>= w;
+                    bits -= w;
+                    raw += d;
+                    run += d + (uint32_t)min_delta;
+                    summed += run;
+                }
+                r.p += have;
+            } else {
+                // n deltas of zero: run, run + m, ... with m = min_delta
+                for (uint64_t i = 0; i < n; i++) { run += (uint32_t)min_delta; summed += run; }
+            }
+            left -= n;
+            if (left == 0) break;
+        }
+        last = run;
+        sum += summed;
+    }
+    *consumed = (uint64_t)(r.p - src);
+    return sum;
 }
 
 } // namespace
@@ -167,43 +285,19 @@ int pqd_decode_fixed_len_byte_array(pqd_ctx* ctx, int encoding, int size, const 
 int64_t pqd_estimate_decode_byte_array_size(pqd_ctx* ctx, int encoding, const uint8_t* src, uint64_t src_len) {
     // plain.go:106-108: PLAIN answers len(src).  The DELTA encodings sum their length
     // streams with wrapping int32 arithmetic (delta.go:28-33; length_byte_array.go:65-70,
-    // byte_array.go:176-183): the streams are decoded and summed on the device.
+    // byte_array.go:176-183).  The streams are a few bytes per value and the page is in host
+    // memory: they are walked where they lie, with no trip to the device.
+    (void)ctx;
     if (encoding == PQD_ENC_PLAIN) return (int64_t)src_len;
     if (encoding != PQD_ENC_DELTA_LENGTH_BYTE_ARRAY && encoding != PQD_ENC_DELTA_BYTE_ARRAY) return 0;
-    if (ctx == nullptr || (src == nullptr && src_len > 0)) return 0;
-    DeviceGuard guard(ctx->device);
-    if (!guard.ok) return 0;
-    DevMem dsrc, dsum;
-    if (!dsrc.alloc(src_len + 32) || !dsum.alloc(16)) return 0;
-    if (src_len && hipMemcpy(dsrc.p, src, src_len, hipMemcpyHostToDevice) != hipSuccess) return 0;
+    if (src == nullptr && src_len > 0) return 0;
     const int streams = encoding == PQD_ENC_DELTA_BYTE_ARRAY ? 2 : 1;
     int64_t total = 0;
     uint64_t at = 0;
     for (int k = 0; k < streams; k++) {
-        uint64_t cap = 4096;
-        pqd_page p;
-        DevMem dlen;
-        for (int attempt = 0; attempt < 2; attempt++) {
-            if (dlen.p) { (void)hipFree(dlen.p); dlen.p = nullptr; }
-            if (!dlen.alloc(cap + 32)) return 0;
-            std::memset(&p, 0, sizeof p);
-            p.src = static_cast<uint8_t*>(dsrc.p) + at; p.src_len = src_len - at;
-            p.dst = dlen.p; p.dst_cap = cap;
-            p.num_values = -1;
-            p.encoding = PQD_ENC_DELTA_BINARY_PACKED; p.kind = PQD_KIND_INT32;
-            if (pqd_decode_batch(ctx, &p, 1, nullptr) != PQD_OK) return 0;
-            if (p.status != PQD_ERR_DST_TOO_SMALL) break;
-            cap = (uint64_t)p.status_arg;
-        }
-        if (p.status == PQD_ERR_DST_TOO_SMALL) return 0;
-        uint32_t sum = 0;
-        if (hipMemset(dsum.p, 0, 4) != hipSuccess) return 0;
-        if (p.out_values > 0) {
-            launch_sum_lengths(static_cast<const int32_t*>(dlen.p), p.out_values, static_cast<uint32_t*>(dsum.p), nullptr);
-            if (hipMemcpy(&sum, dsum.p, 4, hipMemcpyDeviceToHost) != hipSuccess) return 0;
-        }
-        total += (int64_t)(int32_t)sum;
-        at += p.consumed < src_len - at ? p.consumed : src_len - at;
+        uint64_t used = 0;
+        total += (int64_t)(int32_t)sum_delta_int32(src + at, src_len - at, &used);
+        at += used < src_len - at ? used : src_len - at;
     }
     return total;
 }
@@ -252,21 +346,31 @@ int pqd_dict_lookup(pqd_dict* d, const int32_t* indexes, uint64_t n, void* rows,
     if (stride < d->width) return PQD_ERR_INVALID_ARGUMENT;
     DeviceGuard guard(d->ctx->device);
     if (!guard.ok) return PQD_ERR_DEVICE;
-    DevMem didx, drows, dst;
-    if (!didx.alloc(n * 4) || !drows.alloc(n * d->width) || !dst.alloc(16)) return PQD_ERR_DEVICE;
-    if (n && hipMemcpy(didx.p, indexes, n * 4, hipMemcpyHostToDevice) != hipSuccess) return PQD_ERR_DEVICE;
-    int rc = launch_dict_gather(d->values, d->n, d->width, static_cast<const int32_t*>(didx.p), n, drows.p, d->width,
-                                static_cast<int64_t*>(dst.p), nullptr);
-    if (rc != PQD_OK) return rc;
-    int64_t st[2] = {0, 0};
-    if (hipMemcpy(st, dst.p, 16, hipMemcpyDeviceToHost) != hipSuccess) return PQD_ERR_DEVICE;
+    Lease lease(d->ctx);
+    Workspace* ws = lease.ws;
+    if (ws == nullptr) return PQD_ERR_DEVICE;
+    const size_t o_idx = 0, o_rows = pad256(n * 4), o_st = o_rows + pad256(n * d->width);
+    if (!ws->reserve_io(o_st + 256)) return PQD_ERR_DEVICE;
+    uint8_t* d_io = static_cast<uint8_t*>(ws->d_io);
+    uint8_t* h_io = static_cast<uint8_t*>(ws->h_io);
+    if (n) {
+        std::memcpy(h_io + o_idx, indexes, n * 4);
+        PQD_HIP(hipMemcpyAsync(d_io + o_idx, h_io + o_idx, n * 4, hipMemcpyHostToDevice, ws->stream));
+    }
+    int rc = launch_dict_gather(d->values, d->n, d->width, reinterpret_cast<const int32_t*>(d_io + o_idx), n, d_io + o_rows,
+                                d->width, reinterpret_cast<int64_t*>(d_io + o_st), ws->stream);
+    if (rc != PQD_OK) { (void)hipStreamSynchronize(ws->stream); return rc; }
+    // dense gather on the device, strided placement on the host (rows live in host memory here;
+    // the device-pointer variant scatters in the kernel)
+    PQD_HIP(hipMemcpyAsync(h_io + o_rows, d_io + o_rows, n * d->width + (o_st - o_rows - n * d->width) + 16, hipMemcpyDeviceToHost, ws->stream));
+    PQD_HIP(hipStreamSynchronize(ws->stream));
+    int64_t st[2];
+    std::memcpy(st, h_io + o_st, 16);
     if (st[0] != PQD_OK) { if (status_arg) *status_arg = st[1]; return (int)st[0]; }
-    // dense gather on the device, strided placement on the host (rows live in
-    // host memory here; the device-pointer variant scatters in the kernel)
-    std::vector<uint8_t> dense(n * d->width);
-    if (n && hipMemcpy(dense.data(), drows.p, n * d->width, hipMemcpyDeviceToHost) != hipSuccess) return PQD_ERR_DEVICE;
     uint8_t* r = static_cast<uint8_t*>(rows);
-    for (uint64_t i = 0; i < n; i++) std::memcpy(r + i * stride, dense.data() + i * d->width, d->width);
+    const uint8_t* dense = h_io + o_rows;
+    if (stride == d->width) std::memcpy(r, dense, n * d->width);
+    else for (uint64_t i = 0; i < n; i++) std::memcpy(r + i * stride, dense + i * d->width, d->width);
     return PQD_OK;
 }
 

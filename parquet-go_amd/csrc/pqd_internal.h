@@ -4,7 +4,19 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
 #include "../../include/pqd.h"
+
+namespace pqd { struct Workspace; }
+
+#define PQD_HIP(call)                                   \
+    do {                                                \
+        hipError_t e_ = (call);                         \
+        if (e_ != hipSuccess) return PQD_ERR_DEVICE;    \
+    } while (0)
 
 // Opaque handles of the C ABI.
 struct pqd_ctx {
@@ -14,6 +26,8 @@ struct pqd_ctx {
     int32_t dict_lds;     // dictionary pages through an LDS-resident dictionary: 0 never, 1 when it pays, 2 whenever possible
     uint64_t dict_lds_max_bytes; // dictionaries above this size never take that path
     uint64_t dict_lds_cap_bytes; // at most this much of a dictionary is kept in LDS (0: all that fits)
+    std::mutex mu;                          // guards the list below
+    std::vector<struct pqd::Workspace*> idle; // workspaces of the host entry points that no call is using
     void* levels_scratch; // this device's copy of the static workspace of pqd_optional_expand_noalloc (null: look-up failed)
 };
 
@@ -188,6 +202,44 @@ __device__ inline void set_status(DevResult* r, int32_t status, int64_t arg) {
     r->status = status;
     r->arg = arg;
 }
+
+// Device and pinned host memory one caller of the host entry points keeps from call to call,
+// with a stream of its own: nothing is allocated per call once the buffers have grown to the
+// sizes the caller's pages need.
+struct Workspace {
+    hipStream_t stream = nullptr;
+    void* arena = nullptr;  size_t arena_cap = 0;   // the batch's arena
+    void* pinned = nullptr; size_t pinned_cap = 0;  // host image of the arena's uploaded part; results read back
+    void* d_io = nullptr;   size_t d_io_cap = 0;    // device staging of a page: source, destination, offsets
+    void* h_io = nullptr;   size_t h_io_cap = 0;    // the same in pinned host memory
+    static bool grow(void** p, size_t* cap, size_t need, bool host) {
+        if (need <= *cap) return true;
+        const size_t want = std::max(need + need / 2, (size_t)1 << 16);
+        void* q = nullptr;
+        if ((host ? hipHostMalloc(&q, want, hipHostMallocDefault) : hipMalloc(&q, want)) != hipSuccess) return false;
+        if (*p) (void)(host ? hipHostFree(*p) : hipFree(*p));
+        *p = q;
+        *cap = want;
+        return true;
+    }
+    bool reserve_arena(size_t n) { return grow(&arena, &arena_cap, n, false); }
+    bool reserve_pinned(size_t n) { return grow(&pinned, &pinned_cap, n, true); }
+    bool reserve_io(size_t n) { return grow(&d_io, &d_io_cap, n, false) && grow(&h_io, &h_io_cap, n, true); }
+    void release() {
+        if (arena) (void)hipFree(arena);
+        if (d_io) (void)hipFree(d_io);
+        if (pinned) (void)hipHostFree(pinned);
+        if (h_io) (void)hipHostFree(h_io);
+        if (stream) (void)hipStreamDestroy(stream);
+        arena = d_io = pinned = h_io = nullptr;
+        stream = nullptr;
+    }
+};
+int batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, pqd_batch** out, Workspace* ws);
+int batch_finish_ws(pqd_batch* b, Workspace* ws, pqd_page* pages);
+void batch_report(pqd_batch* b, const struct DevResult* results, pqd_page* pages);
+Workspace* workspace_acquire(pqd_ctx* ctx); // a free workspace of the context (a new one when all are in use); nullptr on failure
+void workspace_release(pqd_ctx* ctx, Workspace* ws);
 
 // Kernel launchers (defined in the .hip files).
 void launch_delta(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, bool is64,

@@ -1,5 +1,9 @@
-"""PCIe-inclusive rate of the per-method host wrapper (host src -> host dst), for the record."""
-import os, sys, time
+"""PCIe-inclusive rates of the per-method host entry points (host src -> host dst), for the record:
+one call per page as a cgo binding of encoding.Encoding makes them, at the reference's page size
+(1 MiB of decoded values) from 1 and from 16 host threads, then one very large page, then the same
+bytes through a reader's own pinned staging and the batched device API."""
+import ctypes as C
+import os, sys, threading, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as entry
@@ -7,7 +11,103 @@ import bench
 
 pkg = entry.load_package()
 from parquet_go_amd import encoding as E
+from oracle import pqoracle as O
 rng = np.random.default_rng(1)
+L = pkg.lib()
+ctx = pkg.Context(0)
+H = ctx.handle
+VP = C.c_void_p
+
+
+def _ptr(a):
+    return VP(a.ctypes.data)
+
+
+def per_call(name, call_of, out_bytes, threads, seconds=2.0):
+    """call_of(t) -> a zero-argument function making ONE library call with thread t's own buffers."""
+    calls = [call_of(t) for t in range(threads)]
+    for c in calls:
+        for _ in range(3):
+            assert c() == 0
+    counts = [0] * threads
+    start = threading.Barrier(threads + 1)
+    stop = [False]
+
+    def work(t):
+        start.wait()
+        c, k = calls[t], 0
+        while not stop[0]:
+            c()
+            k += 1
+        counts[t] = k
+
+    ts = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+    for t in ts:
+        t.start()
+    start.wait()
+    t0 = time.perf_counter()
+    time.sleep(seconds)
+    stop[0] = True
+    for t in ts:
+        t.join()
+    dt = time.perf_counter() - t0
+    n = sum(counts)
+    print(f"  {name:34s} {threads:2d} thread(s): {n / dt:9.0f} calls/s, {dt / n * threads * 1e6:8.1f} us per call, "
+          f"{n * out_bytes / dt / 1e9:6.2f} GB/s decoded", flush=True)
+
+
+PAGE = 131072  # 1 MiB of int64 values: the reference's default page size
+ts_vals = 1_600_000_000_000_000_000 + np.cumsum(rng.integers(1_000_000, 1_004_096, size=PAGE, dtype=np.int64))
+delta_page = np.frombuffer(bench.delta_page_int64(ts_vals), np.uint8).copy()
+plain_page = ts_vals.view(np.uint8).copy()
+idx = rng.integers(0, 65536, size=PAGE * 2, dtype=np.int32)
+rle_page = np.frombuffer(bytes(O.rle_dict_encode_int32(idx)), np.uint8).copy()
+strs = [b"https://www.example.com/catalog/items/%08d" % int(v) for v in rng.integers(0, 10**8, size=PAGE // 6)]
+dlba_page = np.frombuffer(bytes(O.dlba_encode(strs)), np.uint8).copy()
+str_bytes = sum(map(len, strs))
+small_vals = ts_vals[:1024].copy()
+small_page = np.frombuffer(bench.delta_page_int64(small_vals), np.uint8).copy()
+
+
+def fixed(fn, code, page, n_out, dtype, *pre):
+    def make(t):
+        dst = np.empty(n_out, dtype)
+        nb, arg = C.c_uint64(0), C.c_int64(0)
+        args = (H, code) + pre + (_ptr(page), C.c_uint64(page.size), _ptr(dst), C.c_uint64(dst.nbytes), C.byref(nb), C.byref(arg))
+        return lambda keep=(dst, page): fn(*args)
+    return make
+
+
+def byte_array(code, page, n_bytes, n_vals):
+    def make(t):
+        dst = np.empty(n_bytes, np.uint8)
+        off = np.empty(n_vals + 1, np.uint32)
+        nb, no, arg = C.c_uint64(0), C.c_uint64(0), C.c_int64(0)
+        args = (H, code, _ptr(page), C.c_uint64(page.size), _ptr(dst), C.c_uint64(dst.size), _ptr(off), C.c_uint64(off.size),
+                C.byref(nb), C.byref(no), C.byref(arg))
+        return lambda keep=(dst, off, page): L.pqd_decode_byte_array(*args)
+    return make
+
+
+def estimate(code, page):
+    def make(t):
+        args = (H, code, _ptr(page), C.c_uint64(page.size))
+        want = str_bytes
+        return lambda: 0 if L.pqd_estimate_decode_byte_array_size(*args) == want else 1
+    return make
+
+
+check = np.empty(PAGE, np.int64)
+assert np.array_equal(E.DeltaBinaryPacked().DecodeInt64(check, delta_page), ts_vals)
+print("per-call host entry points, pageable caller memory, pages of 1 MiB decoded (staging, stream and arena from the context's pool):")
+for threads in (1, 16):
+    per_call("DELTA_BINARY_PACKED int64 1 MiB", fixed(L.pqd_decode_int64, pkg.ENC.DELTA_BINARY_PACKED, delta_page, PAGE, np.int64), PAGE * 8, threads)
+    per_call("PLAIN int64 1 MiB", fixed(L.pqd_decode_int64, pkg.ENC.PLAIN, plain_page, PAGE, np.int64), PAGE * 8, threads)
+    per_call("RLE_DICTIONARY indexes 1 MiB", fixed(L.pqd_decode_int32, pkg.ENC.RLE_DICTIONARY, rle_page, PAGE * 2, np.int32, 0), PAGE * 8, threads)
+    per_call("DELTA_LENGTH_BYTE_ARRAY ~1 MiB", byte_array(pkg.ENC.DELTA_LENGTH_BYTE_ARRAY, dlba_page, str_bytes, len(strs)), str_bytes, threads)
+    per_call("estimate DELTA_LENGTH_BYTE_ARRAY", estimate(pkg.ENC.DELTA_LENGTH_BYTE_ARRAY, dlba_page), str_bytes, threads)
+    per_call("DELTA_BINARY_PACKED int64 8 KiB", fixed(L.pqd_decode_int64, pkg.ENC.DELTA_BINARY_PACKED, small_page, 1024, np.int64), 8192, threads)
+
 n = 16 << 20
 ts = 1_600_000_000_000_000_000 + np.cumsum(rng.integers(1_000_000, 1_004_096, size=n, dtype=np.int64))
 page = bench.delta_page_int64(ts)
@@ -20,8 +120,8 @@ for _ in range(5):
     t0 = time.perf_counter()
     codec.DecodeInt64(dst, page)
     best = min(best, time.perf_counter() - t0)
-print(f"host wrapper, one DELTA int64 page of {n} values ({len(page)/1e6:.1f} MB in, {dst.nbytes/1e6:.1f} MB out): "
-      f"{best*1e3:.2f} ms = {dst.nbytes/best/1e9:.2f} GB/s decoded, pageable host memory, hipMalloc/hipFree per call")
+print(f"host entry point, one DELTA int64 page of {n} values ({len(page)/1e6:.1f} MB in, {dst.nbytes/1e6:.1f} MB out): "
+      f"{best*1e3:.2f} ms = {dst.nbytes/best/1e9:.2f} GB/s decoded, pageable caller memory")
 
 # The same job as a reader with its own staging would run it: the headline batch (2048 DELTA pages)
 # in eight slices, pinned host buffers, copy in -> decode -> copy out on three streams so that the
@@ -29,7 +129,6 @@ print(f"host wrapper, one DELTA int64 page of {n} values ({len(page)/1e6:.1f} MB
 import torch  # noqa: E402
 
 
-ctx = pkg.Context(0)
 dev = "cuda:0"
 vals = [1_600_000_000_000_000_000 + np.cumsum(rng.integers(1_000_000, 1_004_096, size=131072, dtype=np.int64)) for _ in range(16)]
 pages = [bench.delta_page_int64(v) for v in vals]
