@@ -1,0 +1,226 @@
+"""The Go package under go/ cannot be compiled in this image (no Go toolchain), so what can be
+checked mechanically is: every `C.pqd_*` call names a function of include/pqd.h with the right
+number of arguments, every `C.PQD_*` constant and `C.pqd_*` type exists in the headers, the struct
+fields the Go code touches exist, the nine codecs define the Decode methods the tested Python
+mirror of the same surface defines, every status has its Go error, and the patches still apply to
+the files of the reference they name."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GO_DIRS = [os.path.join(ROOT, "go", "pqd"), os.path.join(ROOT, "go", "parquet")]
+
+
+def _go_files():
+    out = []
+    for d in GO_DIRS:
+        out += [os.path.join(d, f) for f in sorted(os.listdir(d)) if f.endswith(".go")]
+    return out
+
+
+def _strip_c_comments(text):
+    return re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+
+
+def _strip_go(text):
+    """Go source without comments and string literals (the cgo preamble is a comment and goes too)."""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            i = text.find("*/", i) + 2
+        elif c == '"':
+            j = i + 1
+            while text[j] != '"':
+                j += 2 if text[j] == "\\" else 1
+            out.append('""')
+            i = j + 1
+        elif c == "`":
+            i = text.find("`", i + 1) + 1
+            out.append('""')
+        elif c == "'":
+            j = i + 1
+            while text[j] != "'":
+                j += 2 if text[j] == "\\" else 1
+            out.append("' '")
+            i = j + 1
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out)
+
+
+def _split_args(s):
+    args, depth, cur = [], 0, []
+    for c in s:
+        if c in "([{":
+            depth += 1
+        elif c in ")]}":
+            depth -= 1
+        if c == "," and depth == 0:
+            args.append("".join(cur).strip())
+            cur = []
+        else:
+            cur.append(c)
+    last = "".join(cur).strip()
+    if last:
+        args.append(last)
+    return args
+
+
+def _call_args(text, open_paren):
+    depth = 0
+    for j in range(open_paren, len(text)):
+        if text[j] in "([{":
+            depth += 1
+        elif text[j] in ")]}":
+            depth -= 1
+            if depth == 0:
+                return _split_args(text[open_paren + 1: j])
+    raise AssertionError("unbalanced call")
+
+
+def _prototypes():
+    text = _strip_c_comments(open(os.path.join(ROOT, "include", "pqd.h")).read())
+    protos = {}
+    for m in re.finditer(r"\b(pqd_[a-z0-9_]+)\s*\(", text):
+        args = _call_args(text, m.end() - 1)
+        protos[m.group(1)] = 0 if args == ["void"] else len(args)
+    return protos
+
+
+def _header_text():
+    return "".join(_strip_c_comments(open(os.path.join(ROOT, "include", f)).read()) for f in ("pqd.h", "pqd_status.h"))
+
+
+def _struct_fields(name):
+    text = _header_text()
+    m = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, flags=re.S)
+    assert m, name
+    return set(re.findall(r"([a-z_0-9]+)\s*;", m.group(1)))
+
+
+def test_go_sources_are_there():
+    names = {os.path.basename(f) for f in _go_files()}
+    assert {"pqd.go", "errors.go", "decode.go", "encodings.go", "dictionary.go", "batch.go", "chunk.go", "device.go",
+            "pages_pqd.go"} <= names
+    for f in _go_files():
+        text = _strip_go(open(f).read())
+        for a, b in ("()", "[]", "{}"):
+            assert text.count(a) == text.count(b), (f, a)
+        assert re.search(r"^package (pqd|parquet)$", text, flags=re.M), f
+
+
+def test_every_c_call_matches_a_prototype():
+    protos = _prototypes()
+    assert len(protos) >= 30
+    called = {}
+    for f in _go_files():
+        text = _strip_go(open(f).read())
+        for m in re.finditer(r"\bC\.(pqd_[a-z0-9_]+)\(", text):
+            name = m.group(1)
+            assert name in protos, f"{os.path.basename(f)}: C.{name} is not declared in include/pqd.h"
+            got = len(_call_args(text, m.end() - 1))
+            # a C.pqd_page{} / C.pqd_column_info{...} literal is not a call; conversions C.pqd_x(...) do not occur
+            assert got == protos[name], f"{os.path.basename(f)}: C.{name} called with {got} arguments, the header declares {protos[name]}"
+            called[name] = called.get(name, 0) + 1
+    # the whole host surface and the batch surface are bound
+    for name in ("pqd_ctx_create", "pqd_ctx_destroy", "pqd_abi_version", "pqd_status_name", "pqd_decode_levels", "pqd_decode_boolean",
+                 "pqd_decode_int32", "pqd_decode_int64", "pqd_decode_int96", "pqd_decode_float", "pqd_decode_double",
+                 "pqd_decode_byte_array", "pqd_decode_fixed_len_byte_array", "pqd_estimate_decode_byte_array_size",
+                 "pqd_can_decode_in_place", "pqd_dict_create", "pqd_dict_destroy", "pqd_dict_lookup", "pqd_batch_create",
+                 "pqd_batch_launch", "pqd_batch_finish", "pqd_batch_destroy", "pqd_chunk_scan_pages", "pqd_chunk_plan_pages"):
+        assert called.get(name), f"no Go binding calls {name}"
+
+
+def test_constants_types_and_fields_exist():
+    header = _header_text()
+    constants = set(re.findall(r"\b(PQD_[A-Z0-9_]+)\b", header))
+    types = set(re.findall(r"typedef struct (pqd_[a-z_]+)", header))
+    fields = {"p": _struct_fields("pqd_page"), "r": _struct_fields("pqd_page_header"),
+              "info": _struct_fields("pqd_column_info"), "part": _struct_fields("pqd_page_part")}
+    for f in _go_files():
+        text = _strip_go(open(f).read())
+        for name in re.findall(r"\bC\.(PQD_[A-Z0-9_]+)\b", text):
+            assert name in constants, f"{os.path.basename(f)}: C.{name} is not in the headers"
+        for name in re.findall(r"\bC\.(pqd_[a-z0-9_]+)\b(?!\()", text):
+            assert name in types, f"{os.path.basename(f)}: C.{name} is not a type of include/pqd.h"
+        if os.path.basename(f) in ("batch.go", "chunk.go"):
+            for var, name in re.findall(r"\b(p|r)\.(_?[a-z][a-z_0-9]*)\b", text):
+                assert name.lstrip("_") in fields[var], f"{os.path.basename(f)}: {var}.{name} is not a field"
+    chunk = _strip_go(open(os.path.join(ROOT, "go", "pqd", "chunk.go")).read())
+    lit = re.search(r"C\.pqd_column_info\{(.*?)\}", chunk, flags=re.S).group(1)
+    assert set(re.findall(r"([a-z_]+):", lit)) == fields["info"]
+    for name in re.findall(r"parts\[i\]\.([a-z_]+)", chunk):
+        assert name in fields["part"]
+
+
+DECODE_METHODS = ("DecodeLevels", "DecodeBoolean", "DecodeInt32", "DecodeInt64", "DecodeInt96", "DecodeFloat", "DecodeDouble",
+                  "DecodeByteArray", "DecodeFixedLenByteArray", "EstimateDecodeByteArraySize")
+
+
+def test_codecs_define_what_the_python_mirror_defines():
+    import __graft_entry__ as entry
+    entry.load_package()
+    from parquet_go_amd import encoding as E
+    text = _strip_go(open(os.path.join(ROOT, "go", "pqd", "encodings.go")).read())
+    codecs = ("Plain", "PlainDictionary", "RLE", "RLEDictionary", "BitPacked", "DeltaBinaryPacked", "DeltaLengthByteArray",
+              "DeltaByteArray", "ByteStreamSplit")
+    names = {"Plain": "PLAIN", "PlainDictionary": "PLAIN_DICTIONARY", "RLE": "RLE", "RLEDictionary": "RLE_DICTIONARY",
+             "BitPacked": "BIT_PACKED", "DeltaBinaryPacked": "DELTA_BINARY_PACKED", "DeltaLengthByteArray": "DELTA_LENGTH_BYTE_ARRAY",
+             "DeltaByteArray": "DELTA_BYTE_ARRAY", "ByteStreamSplit": "BYTE_STREAM_SPLIT"}
+    raw = open(os.path.join(ROOT, "go", "pqd", "encodings.go")).read()
+    for codec in codecs:
+        assert re.search(r"type %s struct \{\s*encoding\.NotSupported\b" % codec, text), f"{codec} does not embed encoding.NotSupported"
+        go = set(re.findall(r"func \(e \*%s\) (\w+)\(" % codec, text))
+        cls = getattr(E, codec)
+        py = {m for m in DECODE_METHODS if getattr(cls, m) is not getattr(E.Encoding, m)}
+        assert go & set(DECODE_METHODS) == py, (codec, sorted(go), sorted(py))
+        assert {"String", "Encoding"} <= go
+        assert 'func (e *%s) String() string            { return "%s" }' % (codec, names[codec]) in raw or \
+            re.search(r'func \(e \*%s\) String\(\) string\s*\{ return "%s" \}' % (codec, names[codec]), raw), codec
+        assert cls.NAME == names[codec]
+    # the level tables: widths 1..8, as encoding.go:64-85
+    for table in ("LevelEncodingsRLE", "LevelEncodingsBitPacked"):
+        body = re.search(r"var %s = \[\.\.\.\]\w+\{(.*?)\n\}" % table, text, flags=re.S).group(1)
+        assert re.findall(r"(\d): \{BitWidth: (\d)\}", body) == [(str(i), str(i + 1)) for i in range(8)]
+
+
+def test_every_status_has_a_go_error():
+    status = _strip_c_comments(open(os.path.join(ROOT, "include", "pqd_status.h")).read())
+    codes = re.findall(r"\b(PQD_ERR_[A-Z_]+) = \d+", status)
+    assert len(codes) == 19
+    errors = _strip_go(open(os.path.join(ROOT, "go", "pqd", "errors.go")).read())
+    decode = _strip_go(open(os.path.join(ROOT, "go", "pqd", "decode.go")).read())
+    for code in codes:
+        where = decode if code in ("PQD_ERR_DST_TOO_SMALL", "PQD_ERR_OFFSETS_TOO_SMALL") else errors
+        assert f"C.{code}" in where, code
+    for name in re.findall(r"\b(PQD_EOF_[A-Z_]+|PQD_DELTA_[A-Z_]+) = \d+", status):
+        assert f"C.{name}" in errors, name
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference"), reason="the reference tree is not here")
+def test_patches_apply_to_the_reference():
+    for patch in ("encodings.diff", "dictionary_lookup.diff"):
+        text = open(os.path.join(ROOT, "patches", patch)).read()
+        files = re.split(r"^--- a/", text, flags=re.M)[1:]
+        assert files
+        for part in files:
+            name = part.split("\n", 1)[0].strip()
+            ref = open(os.path.join("/root/reference", name)).read().split("\n")
+            for hunk in re.split(r"^@@ ", part, flags=re.M)[1:]:
+                head, body = hunk.split("\n", 1)
+                start = int(re.match(r"-(\d+)", head).group(1))
+                old = [line[1:] for line in body.split("\n") if line[:1] in (" ", "-")]
+                while old and old[-1] == "":
+                    old.pop()
+                assert ref[start - 1: start - 1 + len(old)] == old, (patch, name, start)
+    enc = open(os.path.join(ROOT, "patches", "encodings.diff")).read()
+    for codec in ("Plain", "PlainDictionary", "BitPacked", "RLE", "RLEDictionary", "DeltaBinaryPacked", "DeltaLengthByteArray",
+                  "DeltaByteArray", "ByteStreamSplit"):
+        assert f"&pqd.{codec}{{}}" in enc, codec
