@@ -201,6 +201,54 @@ int pqd_dict_lookup_bytes_device(pqd_ctx* ctx, int32_t kind, const void* dict_de
                                  uint64_t dst_cap, uint32_t* offsets_dev, uint64_t offsets_cap, int64_t* status_dev,
                                  void* hip_stream);
 
+/* ---- encoders and page statistics, device-resident ------------------------ */
+
+/*
+ * One page to encode: `n_values` values at `src` (int32 / int64 / float / double, or
+ * n_values * bit_width bytes of FIXED_LEN_BYTE_ARRAY values) become the page bytes the
+ * reference's Encode methods produce (encoding/encoding.go:29-41), byte for byte:
+ *   PQD_ENC_DELTA_BINARY_PACKED, kind INT32 / INT64: blocks of 128 values in 4 miniblocks
+ *     (delta.BinaryPackedEncoding.EncodeInt32 / EncodeInt64, encoding/delta/binary_packed.go:26-34, 77-277);
+ *   PQD_ENC_RLE_DICTIONARY, kind INT32: a bit-width byte and the RLE / bit-packed hybrid of the
+ *     dictionary indexes (rle.DictionaryEncoding.EncodeInt32, encoding/rle/dictionary.go:23-28, 52-59,
+ *     encoding/rle/rle.go:203-249);
+ *   PQD_ENC_BYTE_STREAM_SPLIT, kind INT32 / INT64 / FLOAT / DOUBLE / FIXED_LEN_BYTE_ARRAY
+ *     (encoding/bytestreamsplit/bytestreamsplit.go:19-33, bytestreamsplit_amd64.s:56-208).
+ * Other combinations answer PQD_ERR_NOT_SUPPORTED, as encoding.NotSupported does.
+ * All pointers are device pointers; `src` is aligned to the value width (4 or 8 bytes) except
+ * for BYTE_STREAM_SPLIT, `dst` may have any alignment.  PQD_ERR_DST_TOO_SMALL: status_arg = bytes
+ * the page needs.
+ */
+typedef struct pqd_encode_page {
+    const void* src;
+    uint64_t    n_values;
+    void*       dst;
+    uint64_t    dst_cap;
+    int32_t     encoding;  /* pqd_encoding */
+    int32_t     kind;      /* pqd_kind */
+    int32_t     bit_width; /* FIXED_LEN_BYTE_ARRAY: the type length */
+    /* results */
+    int32_t     status;
+    int64_t     status_arg;
+    uint64_t    out_bytes;
+} pqd_encode_page;
+
+/* The largest page `n_values` values can encode to (0: not supported). */
+uint64_t pqd_encode_bound(int encoding, int kind, int bit_width, uint64_t n_values);
+
+/* Bytes of device scratch pqd_encode_batch needs for these pages (src, dst are not looked at). */
+uint64_t pqd_encode_workspace_size(const pqd_encode_page* pages, uint64_t n_pages);
+
+/* Encodes the pages on `hip_stream`, waits, and fills their result fields.  `workspace_dev` is
+ * caller-owned device scratch of at least pqd_encode_workspace_size bytes; nothing is allocated. */
+int pqd_encode_batch(pqd_ctx* ctx, pqd_encode_page* pages, uint64_t n_pages, void* workspace_dev,
+                     uint64_t workspace_bytes, void* hip_stream);
+
+/* One page, host pointers in and out: the Encode method of encoding.Encoding that `encoding`
+ * and `kind` name.  Go's "may grow dst" is PQD_ERR_DST_TOO_SMALL with the size in *status_arg. */
+int pqd_encode_values(pqd_ctx* ctx, int encoding, int kind, int bit_width, const void* src, uint64_t n_values,
+                      uint8_t* dst, uint64_t dst_cap, uint64_t* out_bytes, int64_t* status_arg);
+
 /* ---- definition and repetition levels, device-resident ------------------ */
 
 /*

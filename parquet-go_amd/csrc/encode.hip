@@ -1,0 +1,513 @@
+// encode.hip -- page encoders for gfx950, byte for byte what the reference's writers produce:
+//
+//   DELTA_BINARY_PACKED int32 / int64   delta.BinaryPackedEncoding.EncodeInt32 / EncodeInt64
+//                                       (encoding/delta/binary_packed.go:26-34, 77-181, 183-277):
+//                                       blocks of 128 values in 4 miniblocks of 32
+//   RLE_DICTIONARY index pages          rle.DictionaryEncoding.EncodeInt32
+//                                       (encoding/rle/dictionary.go:23-28, 52-59) over encodeInt32
+//                                       (encoding/rle/rle.go:203-249)
+//   BYTE_STREAM_SPLIT                   bytestreamsplit.Encoding.Encode{Int32,Int64,Float,Double,
+//                                       FixedLenByteArray} (encoding/bytestreamsplit/bytestreamsplit.go:19-33,
+//                                       bytestreamsplit_purego.go:7-45, bytestreamsplit_amd64.s:56-208)
+//
+// and the page statistics of dictionary-encoded columns:
+//
+//   dictionaryBounds*                   min and max of dict[indexes[i]] (dictionary_purego.go:68-170,
+//                                       dictionary_amd64.s:8-575)
+//
+// The variable-length encoders run in one pass over the values.  A page is cut into tiles; a
+// workgroup encodes its tile into LDS, which tells it the tile's size; the place of the tile in
+// the page comes from the sizes of the tiles before it, which the workgroups of a page publish
+// in a per-tile state word and look back over (aggregate first, inclusive prefix once known);
+// then the staged bytes are copied to the page.  The workgroups of a page have consecutive
+// block indexes and a workgroup only ever waits for lower ones.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "pqd_internal.h"
+
+namespace pqd {
+namespace {
+
+constexpr int ET = 256;              // threads per workgroup
+constexpr uint32_t DE_BLOCK = 128;   // values per block (binary_packed.go:18-22)
+constexpr uint32_t DE_MINI = 32;     // values per miniblock
+constexpr uint32_t DE_TILE_BLOCKS = 16; // blocks per workgroup
+
+// One page to encode, as the kernels see it.
+struct EncPage {
+    const uint8_t* src;
+    uint64_t n_values;
+    uint8_t* dst;
+    uint64_t dst_cap;
+    int32_t encoding;
+    int32_t kind;
+    int32_t width;     // bytes per value
+    int32_t family;
+    uint64_t tile_base; // first tile of the page in its family's grid
+    uint64_t n_tiles;
+    // results
+    int32_t status;
+    int32_t bw;        // RLE_DICTIONARY: OR of all indexes while the page is scanned, then unused
+    int64_t arg;
+    uint64_t out_bytes;
+    // RLE_DICTIONARY scratch
+    uint32_t* first_start; // per tile: first group of the tile that starts a run, or ~0
+    uint32_t* next_start;  // per tile: first run start after the tile
+    uint32_t* or_word;     // OR of all indexes of the page
+};
+
+enum EncFamily : int32_t { EF_NONE = 0, EF_DELTA32 = 1, EF_DELTA64 = 2, EF_RLE_DICT = 3, EF_BSS = 4, EF_N = 5 };
+
+constexpr uint64_t ST_AGGREGATE = 1ull << 62, ST_INCLUSIVE = 2ull << 62, ST_FLAGS = 3ull << 62;
+
+__device__ inline void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ inline uint32_t bits_len64(uint64_t v) { return v ? 64u - (uint32_t)__builtin_clzll(v) : 0u; }
+
+__device__ inline uint32_t uvarint_len(uint64_t v) { return v ? (bits_len64(v) + 6) / 7 : 1; }
+
+__device__ inline uint64_t zigzag(int64_t v) { return ((uint64_t)v << 1) ^ (uint64_t)(v >> 63); }
+
+// ORs `nbits` (<= 64) bits of v into the staging area at bit position `at`: the area is an array
+// of little-endian dwords, cleared beforehand, so fields may be written in any order by any lane.
+__device__ inline void stage_or(uint32_t* stage, uint64_t at, uint64_t v, uint32_t nbits) {
+    if (nbits == 0) return;
+    const uint32_t w = (uint32_t)(at >> 5), s = (uint32_t)(at & 31);
+    const unsigned __int128 x = (unsigned __int128)v << s;
+    const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), x2 = (uint32_t)(x >> 64);
+    if (x0) atomicOr(&stage[w], x0);
+    if (x1) atomicOr(&stage[w + 1], x1);
+    if (x2) atomicOr(&stage[w + 2], x2);
+}
+
+// Writes a uvarint at byte `at` of the staging area; returns its length.
+__device__ inline uint32_t stage_uvarint(uint32_t* stage, uint64_t at, uint64_t v) {
+    uint32_t n = 0;
+    while (v >= 0x80) {
+        stage_or(stage, 8 * (at + n), (v & 0x7f) | 0x80, 8);
+        v >>= 7;
+        n++;
+    }
+    stage_or(stage, 8 * (at + n), v, 8);
+    return n + 1;
+}
+
+// Copies `n` staged bytes to dst + base (any alignment) with dword stores where they fit.
+__device__ inline void stage_flush(gptr<uint8_t> dst, uint64_t base, const uint32_t* stage, uint32_t n) {
+    gptr<uint8_t> out = dst + base;
+    const uint32_t head = std::min<uint32_t>(n, (uint32_t)((4 - ((uintptr_t)out & 3)) & 3));
+    const uint8_t* bytes = reinterpret_cast<const uint8_t*>(stage);
+    if (threadIdx.x < head) out[threadIdx.x] = bytes[threadIdx.x];
+    const uint32_t words = (n - head) / 4;
+    const uint32_t sh = 8 * (head & 3);
+    const uint32_t w0 = head / 4; // head < 4: 0
+    for (uint32_t i = threadIdx.x; i < words; i += ET) {
+        const uint32_t lo = stage[w0 + i], hi = stage[w0 + i + 1];
+        const uint32_t v = sh ? (lo >> sh) | (hi << (32 - sh)) : lo;
+        *(gptr<uint32_t>)(out + head + 4 * i) = v;
+    }
+    const uint32_t tail0 = head + 4 * words;
+    if (threadIdx.x < n - tail0) out[tail0 + threadIdx.x] = bytes[tail0 + threadIdx.x];
+}
+
+// The prefix of a tile: publishes the tile's own size, then adds up the tiles of the page before
+// it.  Called by the first wavefront of the workgroup; returns the bytes in front of the tile.
+// `tile` is the tile's number within its page, `state` the page's state words.
+__device__ inline uint64_t tile_prefix(unsigned long long* state, uint64_t tile, uint64_t own, uint32_t lane) {
+    if (tile == 0) {
+        if (lane == 0) __hip_atomic_store(&state[0], ST_INCLUSIVE | own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+    }
+    if (lane == 0) __hip_atomic_store(&state[tile], ST_AGGREGATE | own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t before = 0;
+    uint64_t hi = tile; // tiles [.., hi) are still to be added
+    while (hi > 0) {
+        const uint32_t look = (uint32_t)std::min<uint64_t>(64, hi);
+        unsigned long long s = ST_INCLUSIVE; // lanes with no tile to look at do not hold the others up
+        if (lane < look) {
+            do {
+                s = __hip_atomic_load(&state[hi - 1 - lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((s & ST_FLAGS) == 0) __builtin_amdgcn_s_sleep(2);
+            } while ((s & ST_FLAGS) == 0);
+        }
+        // the nearest tile that already knows its inclusive prefix ends the walk
+        const uint64_t incl = __ballot(lane < look && (s & ST_FLAGS) == ST_INCLUSIVE);
+        const uint32_t stop = incl ? (uint32_t)__builtin_ctzll(incl) : look - 1;
+        uint64_t part = (lane <= stop && lane < look) ? (s & ~ST_FLAGS) : 0;
+        for (int o = 32; o > 0; o >>= 1) part += (uint64_t)__shfl_xor((unsigned long long)part, o);
+        before += part;
+        if (incl) break;
+        hi -= look;
+    }
+    if (lane == 0) __hip_atomic_store(&state[tile], ST_INCLUSIVE | (before + own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return before;
+}
+
+// Finds the page a tile belongs to: prefix[p] <= tile < prefix[p + 1].
+__device__ inline uint32_t page_of_tile(const uint64_t* __restrict__ prefix, uint32_t n_pages, uint64_t tile) {
+    uint32_t lo = 0, hi = n_pages;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) / 2;
+        if (prefix[mid] <= tile) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ---------------------------------------------------------- DELTA_BINARY_PACKED --
+
+template <typename T> struct DeltaOf;
+template <> struct DeltaOf<int32_t> {
+    // differences wrap in 32 bits (binary_packed.go:192-204: blockDeltaInt32 on int32)
+    __device__ static int64_t diff(int32_t a, int32_t b) { return (int64_t)(int32_t)((uint32_t)a - (uint32_t)b); }
+    __device__ static uint64_t rebase(int64_t d, int64_t m) { return (uint32_t)((uint32_t)d - (uint32_t)m); }
+};
+template <> struct DeltaOf<int64_t> {
+    __device__ static int64_t diff(int64_t a, int64_t b) { return (int64_t)((uint64_t)a - (uint64_t)b); }
+    __device__ static uint64_t rebase(int64_t d, int64_t m) { return (uint64_t)d - (uint64_t)m; }
+};
+
+struct DeltaShared {
+    uint32_t size[DE_TILE_BLOCKS];   // encoded bytes of each block of the tile
+    uint32_t head;                   // bytes of the page header (first tile of a page)
+    uint64_t before;                 // bytes of the page in front of this tile
+    // worst case per block: 10 (min delta) + 4 (widths) + 128 * 8; header: 2 + 1 + 10 + 10; two spare dwords
+    uint32_t stage[(DE_TILE_BLOCKS * (14 + DE_BLOCK * 8) + 24) / 4 + 4];
+};
+
+// One workgroup encodes up to 16 blocks (binary_packed.go:105-176): every wavefront takes four
+// of them, a lane two neighbouring values of a block.
+template <typename T>
+__global__ __launch_bounds__(ET) void delta_encode_kernel(EncPage* __restrict__ pages, const uint32_t* __restrict__ items,
+                                                          const uint64_t* __restrict__ prefix, uint32_t n_pages,
+                                                          unsigned long long* __restrict__ state) {
+    __shared__ DeltaShared sh;
+    const uint32_t p = page_of_tile(prefix, n_pages, blockIdx.x);
+    EncPage& pg = pages[items[p]];
+    const uint64_t tile = blockIdx.x - prefix[p];
+    gptr<const T> src = (gptr<const T>)pg.src;
+    const uint64_t n = pg.n_values;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t n_blocks = n < 2 ? 0 : (n - 1 + DE_BLOCK - 1) / DE_BLOCK;
+    const uint64_t block0 = tile * DE_TILE_BLOCKS;
+    const uint32_t blocks = (uint32_t)std::min<uint64_t>(DE_TILE_BLOCKS, n_blocks - std::min(n_blocks, block0));
+
+    constexpr uint32_t PER_WAVE = DE_TILE_BLOCKS / (ET / 64);
+    uint64_t r0[PER_WAVE], r1[PER_WAVE];
+    int64_t min_delta[PER_WAVE];
+    uint32_t widths[PER_WAVE]; // the four miniblock widths of the block, a byte each
+#pragma unroll
+    for (uint32_t j = 0; j < PER_WAVE; j++) {
+        const uint32_t b = wave * PER_WAVE + j;
+        r0[j] = r1[j] = 0; min_delta[j] = 0; widths[j] = 0;
+        if (b >= blocks) continue;
+        const uint64_t k0 = 1 + (block0 + b) * DE_BLOCK + 2 * lane; // index of the lane's first value
+        // the block is padded with zeros before the differences and their minimum are taken (binary_packed.go:139-146)
+        const T prev = src[std::min(k0 - 1, n - 1)];
+        const T v0 = k0 < n ? src[k0] : (T)0;
+        const T v1 = k0 + 1 < n ? src[k0 + 1] : (T)0;
+        const int64_t d0 = k0 <= n ? DeltaOf<T>::diff(v0, prev) : 0;
+        const int64_t d1 = k0 + 1 <= n ? DeltaOf<T>::diff(v1, v0) : 0;
+        int64_t m = std::min(d0, d1);
+        for (int o = 32; o > 0; o >>= 1) m = std::min(m, (int64_t)__shfl_xor((long long)m, o));
+        r0[j] = k0 < n ? DeltaOf<T>::rebase(d0, m) : 0;
+        r1[j] = k0 + 1 < n ? DeltaOf<T>::rebase(d1, m) : 0;
+        uint64_t any = r0[j] | r1[j];
+        for (int o = 8; o > 0; o >>= 1) any |= __shfl_xor((unsigned long long)any, o); // the sixteen lanes of a miniblock
+        const uint32_t bw = bits_len64(any);
+        uint32_t w = 0;
+#pragma unroll
+        for (uint32_t mb = 0; mb < 4; mb++) w |= lane_u32(bw, 16 * mb) << (8 * mb);
+        widths[j] = w;
+        min_delta[j] = m;
+        if (lane == 0)
+            sh.size[b] = uvarint_len(zigzag(m)) + 4 + 4 * ((w & 0xff) + ((w >> 8) & 0xff) + ((w >> 16) & 0xff) + (w >> 24));
+    }
+    const T first = n > 0 ? src[0] : (T)0;
+    if (threadIdx.x == 0)
+        sh.head = tile == 0 ? 2 + 1 + uvarint_len(n) + uvarint_len(zigzag((int64_t)first)) : 0;
+    for (uint32_t i = threadIdx.x; i < sizeof(sh.stage) / 4; i += ET) sh.stage[i] = 0;
+    lds_sync();
+    uint32_t at[PER_WAVE]; // where each of the wave's blocks starts in the staging area
+    uint32_t total = sh.head;
+    {
+        uint32_t run = sh.head;
+#pragma unroll
+        for (uint32_t j = 0; j < PER_WAVE; j++) at[j] = 0;
+#pragma unroll
+        for (uint32_t b = 0; b < DE_TILE_BLOCKS; b++) {
+#pragma unroll
+            for (uint32_t j = 0; j < PER_WAVE; j++) at[j] = b == wave * PER_WAVE + j ? run : at[j];
+            if (b < blocks) run += sh.size[b];
+        }
+        total = run;
+    }
+    if (wave == 0) {
+        const uint64_t before = tile_prefix(state + pg.tile_base, tile, total, lane);
+        if (lane == 0) sh.before = before;
+    }
+    if (tile == 0 && threadIdx.x == 0) { // binary_packed.go:93-103
+        uint32_t o = 0;
+        o += stage_uvarint(sh.stage, o, DE_BLOCK);
+        o += stage_uvarint(sh.stage, o, DE_BLOCK / DE_MINI);
+        o += stage_uvarint(sh.stage, o, n);
+        o += stage_uvarint(sh.stage, o, zigzag((int64_t)first));
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < PER_WAVE; j++) {
+        const uint32_t b = wave * PER_WAVE + j;
+        if (b >= blocks) continue;
+        const uint32_t w = widths[j];
+        uint32_t o = at[j];
+        const uint32_t vl = uvarint_len(zigzag(min_delta[j]));
+        if (lane == 0) {
+            stage_uvarint(sh.stage, o, zigzag(min_delta[j]));
+            stage_or(sh.stage, 8ull * (o + vl), w, 32);
+        }
+        o += vl + 4;
+        const uint32_t mb = lane >> 4;
+        const uint32_t bw = (w >> (8 * mb)) & 0xff;
+        for (uint32_t q = 0; q < mb; q++) o += 4 * ((w >> (8 * q)) & 0xff);
+        const uint64_t bit = 8ull * o + (uint64_t)(2 * (lane & 15)) * bw;
+        stage_or(sh.stage, bit, r0[j], bw);
+        stage_or(sh.stage, bit + bw, r1[j], bw);
+    }
+    lds_sync();
+    const uint64_t before = sh.before;
+    if (before + total <= pg.dst_cap) stage_flush(as_global(pg.dst), before, sh.stage, total);
+    if (tile + 1 == pg.n_tiles && threadIdx.x == 0) {
+        const uint64_t bytes = before + total;
+        pg.out_bytes = bytes <= pg.dst_cap ? bytes : 0;
+        pg.status = bytes <= pg.dst_cap ? PQD_OK : PQD_ERR_DST_TOO_SMALL;
+        pg.arg = bytes <= pg.dst_cap ? 0 : (int64_t)bytes;
+    }
+}
+
+// ------------------------------------------------------------ BYTE_STREAM_SPLIT --
+
+// dst[s * count + k] = src[k * W + s] (bytestreamsplit_purego.go:7-45).  A thread takes four
+// values and writes one dword to each of the W streams.
+template <int W>
+__device__ inline void bss_encode_four(gptr<const uint8_t> src, gptr<uint8_t> dst, uint64_t count, uint64_t k) {
+    uint32_t in[W];
+#pragma unroll
+    for (int d = 0; d < W; d++) in[d] = *(gptr<const uint32_t>)(src + k * W + 4 * d);
+#pragma unroll
+    for (int s = 0; s < W; s++) {
+        uint32_t w = 0;
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int b = e * W + s; // byte of the 4 * W block
+            w |= ((in[b / 4] >> (8 * (b % 4))) & 0xffu) << (8 * e);
+        }
+        gptr<uint8_t> o = dst + (uint64_t)s * count + k;
+        if (((uintptr_t)o & 3) == 0) *(gptr<uint32_t>)o = w;
+        else { o[0] = (uint8_t)w; o[1] = (uint8_t)(w >> 8); o[2] = (uint8_t)(w >> 16); o[3] = (uint8_t)(w >> 24); }
+    }
+}
+
+__global__ __launch_bounds__(ET) void bss_encode_kernel(EncPage* __restrict__ pages, const uint32_t* __restrict__ items) {
+    EncPage& pg = pages[items[blockIdx.x]];
+    const uint64_t width = (uint64_t)pg.width;
+    const uint64_t count = pg.n_values, bytes = count * width;
+    const bool lead = blockIdx.y == 0 && threadIdx.x == 0;
+    if (bytes > pg.dst_cap) {
+        if (lead) { pg.status = PQD_ERR_DST_TOO_SMALL; pg.arg = (int64_t)bytes; pg.out_bytes = 0; }
+        return;
+    }
+    gptr<const uint8_t> src = as_global(pg.src);
+    gptr<uint8_t> dst = as_global(pg.dst);
+    const uint64_t tile = (uint64_t)ET * 4;
+    const bool aligned = ((uintptr_t)pg.src & 3) == 0;
+    for (uint64_t t = blockIdx.y; t * tile < count; t += gridDim.y) {
+        const uint64_t k = t * tile + threadIdx.x * 4;
+        if (k >= count) continue;
+        if (k + 4 <= count && aligned && width == 4) bss_encode_four<4>(src, dst, count, k);
+        else if (k + 4 <= count && aligned && width == 8) bss_encode_four<8>(src, dst, count, k);
+        else {
+            for (uint64_t e = k; e < k + 4 && e < count; e++)
+                for (uint64_t s = 0; s < width; s++) dst[s * count + e] = src[e * width + s];
+        }
+    }
+    if (lead) { pg.status = PQD_OK; pg.arg = 0; pg.out_bytes = bytes; }
+}
+
+} // namespace
+
+// The scratch an encode call needs, and where its parts lie.
+struct EncodePlan {
+    std::vector<EncPage> pages;
+    std::vector<uint32_t> fam_items[EF_N];
+    std::vector<uint64_t> fam_prefix[EF_N]; // per family: first tile of each of its pages, and the total
+    uint64_t bss_max_values = 0;
+    size_t o_pages = 0, o_items[EF_N] = {}, o_prefix[EF_N] = {}, o_state = 0, state_bytes = 0, upload_end = 0, total = 0;
+};
+
+static int32_t value_width(int32_t kind, int32_t bit_width) {
+    switch (kind) {
+        case PQD_KIND_INT32: case PQD_KIND_FLOAT: return 4;
+        case PQD_KIND_INT64: case PQD_KIND_DOUBLE: return 8;
+        case PQD_KIND_INT96: return 12;
+        case PQD_KIND_FIXED_LEN_BYTE_ARRAY: return bit_width;
+        default: return 0;
+    }
+}
+
+static int32_t encode_family(int32_t encoding, int32_t kind, int32_t width) {
+    switch (encoding) {
+        case PQD_ENC_DELTA_BINARY_PACKED:
+            return kind == PQD_KIND_INT32 ? EF_DELTA32 : kind == PQD_KIND_INT64 ? EF_DELTA64 : EF_NONE;
+        case PQD_ENC_BYTE_STREAM_SPLIT:
+            if (kind == PQD_KIND_INT32 || kind == PQD_KIND_INT64 || kind == PQD_KIND_FLOAT || kind == PQD_KIND_DOUBLE) return EF_BSS;
+            return kind == PQD_KIND_FIXED_LEN_BYTE_ARRAY && width > 0 && width <= 32767 ? EF_BSS : EF_NONE;
+        default:
+            return EF_NONE;
+    }
+}
+
+static size_t carve(size_t& off, size_t bytes) {
+    const size_t at = off;
+    off = (off + bytes + 255) & ~(size_t)255;
+    return at;
+}
+
+static void plan_encode(const pqd_encode_page* in, uint64_t n, EncodePlan& plan) {
+    plan.pages.resize(n);
+    for (int f = 0; f < EF_N; f++) plan.fam_prefix[f].assign(1, 0);
+    for (uint64_t i = 0; i < n; i++) {
+        EncPage& e = plan.pages[i];
+        std::memset(&e, 0, sizeof e);
+        e.src = static_cast<const uint8_t*>(in[i].src);
+        e.n_values = in[i].n_values;
+        e.dst = static_cast<uint8_t*>(in[i].dst);
+        e.dst_cap = in[i].dst_cap;
+        e.encoding = in[i].encoding;
+        e.kind = in[i].kind;
+        e.width = value_width(in[i].kind, in[i].bit_width);
+        e.family = encode_family(e.encoding, e.kind, e.width);
+        if ((e.src == nullptr && e.n_values > 0) || (e.dst == nullptr && e.dst_cap > 0)) {
+            e.family = EF_NONE;
+            e.status = PQD_ERR_INVALID_ARGUMENT;
+        } else if (e.family == EF_NONE) {
+            e.status = PQD_ERR_NOT_SUPPORTED; // encoding.NotSupported answers these (encoding/notsupported.go:116-160)
+        } else if (e.family != EF_BSS && ((uintptr_t)e.src & (uintptr_t)(e.width - 1)) != 0) {
+            e.family = EF_NONE;
+            e.status = PQD_ERR_INVALID_ARGUMENT; // typed values are aligned to their width, as a Go slice is
+            e.arg = (int64_t)((uintptr_t)e.src & (uintptr_t)(e.width - 1));
+        } else if ((e.family == EF_DELTA32 || e.family == EF_DELTA64) && e.n_values > 0x7fffffffull) {
+            e.family = EF_NONE;
+            e.status = PQD_ERR_INVALID_ARGUMENT; // the decoder refuses more values than MaxInt32 (binary_packed.go:447-449)
+            e.arg = (int64_t)e.n_values;
+        }
+        if (e.family == EF_NONE) continue;
+        if (e.family == EF_DELTA32 || e.family == EF_DELTA64) {
+            const uint64_t blocks = e.n_values < 2 ? 0 : (e.n_values - 1 + DE_BLOCK - 1) / DE_BLOCK;
+            e.n_tiles = std::max<uint64_t>(1, (blocks + DE_TILE_BLOCKS - 1) / DE_TILE_BLOCKS);
+        } else if (e.family == EF_BSS) {
+            plan.bss_max_values = std::max(plan.bss_max_values, e.n_values);
+        }
+        plan.fam_items[e.family].push_back((uint32_t)i);
+        plan.fam_prefix[e.family].push_back(plan.fam_prefix[e.family].back() + e.n_tiles);
+    }
+    // the state words of all tiled families lie in one block, cleared before every launch
+    uint64_t tiles = 0;
+    for (int f : {EF_DELTA32, EF_DELTA64, EF_RLE_DICT}) {
+        for (size_t k = 0; k < plan.fam_items[f].size(); k++) {
+            plan.pages[plan.fam_items[f][k]].tile_base = tiles + plan.fam_prefix[f][k];
+        }
+        tiles += plan.fam_prefix[f].back();
+    }
+    size_t off = 0;
+    plan.o_pages = carve(off, n * sizeof(EncPage));
+    for (int f = 0; f < EF_N; f++) {
+        plan.o_items[f] = carve(off, plan.fam_items[f].size() * sizeof(uint32_t));
+        plan.o_prefix[f] = carve(off, plan.fam_prefix[f].size() * sizeof(uint64_t));
+    }
+    plan.upload_end = off;
+    plan.state_bytes = tiles * sizeof(unsigned long long);
+    plan.o_state = carve(off, plan.state_bytes);
+    plan.total = off;
+}
+
+} // namespace pqd
+
+using namespace pqd;
+
+extern "C" {
+
+uint64_t pqd_encode_bound(int encoding, int kind, int bit_width, uint64_t n_values) {
+    const int32_t width = value_width(kind, bit_width);
+    switch (encoding) {
+        case PQD_ENC_DELTA_BINARY_PACKED: {
+            // header, then per block of 128 values a min delta, four widths and at most 128 full-width values
+            const uint64_t blocks = n_values < 2 ? 0 : (n_values - 1 + DE_BLOCK - 1) / DE_BLOCK;
+            return 24 + blocks * (14 + (uint64_t)DE_BLOCK * (kind == PQD_KIND_INT64 ? 8 : 4));
+        }
+        case PQD_ENC_BYTE_STREAM_SPLIT:
+            return n_values * (uint64_t)(width > 0 ? width : 0);
+        default:
+            return 0;
+    }
+}
+
+uint64_t pqd_encode_workspace_size(const pqd_encode_page* pages, uint64_t n_pages) {
+    if (pages == nullptr && n_pages > 0) return 0;
+    EncodePlan plan;
+    plan_encode(pages, n_pages, plan);
+    return plan.total + 256;
+}
+
+int pqd_encode_batch(pqd_ctx* ctx, pqd_encode_page* pages, uint64_t n_pages, void* workspace_dev, uint64_t workspace_bytes,
+                     void* hip_stream) {
+    if (ctx == nullptr || (pages == nullptr && n_pages > 0)) return PQD_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return PQD_ERR_DEVICE;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    EncodePlan plan;
+    plan_encode(pages, n_pages, plan);
+    uint8_t* ws = reinterpret_cast<uint8_t*>(((uintptr_t)workspace_dev + 255) & ~(uintptr_t)255);
+    if (workspace_dev == nullptr || (uint64_t)(ws - static_cast<uint8_t*>(workspace_dev)) + plan.total > workspace_bytes)
+        return PQD_ERR_DST_TOO_SMALL;
+    std::vector<uint8_t> image(plan.upload_end, 0);
+    std::memcpy(image.data() + plan.o_pages, plan.pages.data(), n_pages * sizeof(EncPage));
+    for (int f = 0; f < EF_N; f++) {
+        if (!plan.fam_items[f].empty())
+            std::memcpy(image.data() + plan.o_items[f], plan.fam_items[f].data(), plan.fam_items[f].size() * sizeof(uint32_t));
+        std::memcpy(image.data() + plan.o_prefix[f], plan.fam_prefix[f].data(), plan.fam_prefix[f].size() * sizeof(uint64_t));
+    }
+    PQD_HIP(hipMemcpyAsync(ws, image.data(), plan.upload_end, hipMemcpyHostToDevice, s));
+    if (plan.state_bytes) PQD_HIP(hipMemsetAsync(ws + plan.o_state, 0, plan.state_bytes, s));
+    EncPage* d_pages = reinterpret_cast<EncPage*>(ws + plan.o_pages);
+    unsigned long long* d_state = reinterpret_cast<unsigned long long*>(ws + plan.o_state);
+    auto items_of = [&](int f) { return reinterpret_cast<const uint32_t*>(ws + plan.o_items[f]); };
+    auto prefix_of = [&](int f) { return reinterpret_cast<const uint64_t*>(ws + plan.o_prefix[f]); };
+    for (int f : {EF_DELTA32, EF_DELTA64}) {
+        const uint64_t tiles = plan.fam_prefix[f].back();
+        if (tiles == 0) continue;
+        if (tiles > 0x7fffffffull) return PQD_ERR_INVALID_ARGUMENT;
+        const uint32_t np = (uint32_t)plan.fam_items[f].size();
+        if (f == EF_DELTA32)
+            hipLaunchKernelGGL(delta_encode_kernel<int32_t>, dim3((uint32_t)tiles), dim3(ET), 0, s, d_pages, items_of(f), prefix_of(f), np, d_state);
+        else
+            hipLaunchKernelGGL(delta_encode_kernel<int64_t>, dim3((uint32_t)tiles), dim3(ET), 0, s, d_pages, items_of(f), prefix_of(f), np, d_state);
+    }
+    if (!plan.fam_items[EF_BSS].empty()) {
+        const uint64_t per = (uint64_t)ET * 4;
+        const uint32_t gy = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (plan.bss_max_values + per - 1) / per), 1024);
+        hipLaunchKernelGGL(bss_encode_kernel, dim3((uint32_t)plan.fam_items[EF_BSS].size(), gy), dim3(ET), 0, s, d_pages, items_of(EF_BSS));
+    }
+    if (hipGetLastError() != hipSuccess) return PQD_ERR_DEVICE;
+    // results
+    std::vector<EncPage> out(n_pages);
+    if (n_pages) PQD_HIP(hipMemcpyAsync(out.data(), d_pages, n_pages * sizeof(EncPage), hipMemcpyDeviceToHost, s));
+    PQD_HIP(hipStreamSynchronize(s));
+    for (uint64_t i = 0; i < n_pages; i++) {
+        pages[i].status = out[i].status;
+        pages[i].status_arg = out[i].arg;
+        pages[i].out_bytes = out[i].status == PQD_OK ? out[i].out_bytes : 0;
+    }
+    return PQD_OK;
+}
+
+} // extern "C"

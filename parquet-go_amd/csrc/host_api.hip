@@ -302,6 +302,50 @@ int64_t pqd_estimate_decode_byte_array_size(pqd_ctx* ctx, int encoding, const ui
     return total;
 }
 
+int pqd_encode_values(pqd_ctx* ctx, int encoding, int kind, int bit_width, const void* src, uint64_t n_values, uint8_t* dst,
+                      uint64_t dst_cap, uint64_t* out_bytes, int64_t* status_arg) {
+    if (out_bytes) *out_bytes = 0;
+    if (status_arg) *status_arg = 0;
+    if (ctx == nullptr || (src == nullptr && n_values > 0) || (dst == nullptr && dst_cap > 0)) return PQD_ERR_INVALID_ARGUMENT;
+    uint64_t width = 0;
+    switch (kind) {
+        case PQD_KIND_INT32: case PQD_KIND_FLOAT: width = 4; break;
+        case PQD_KIND_INT64: case PQD_KIND_DOUBLE: width = 8; break;
+        case PQD_KIND_FIXED_LEN_BYTE_ARRAY: width = bit_width > 0 ? (uint64_t)bit_width : 0; break;
+        default: break;
+    }
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return PQD_ERR_DEVICE;
+    Lease lease(ctx);
+    Workspace* ws = lease.ws;
+    if (ws == nullptr) return PQD_ERR_DEVICE;
+    pqd_encode_page p;
+    std::memset(&p, 0, sizeof p);
+    p.n_values = n_values; p.dst_cap = dst_cap;
+    p.encoding = encoding; p.kind = kind; p.bit_width = bit_width;
+    const uint64_t src_bytes = n_values * width, scratch = pqd_encode_workspace_size(&p, 1);
+    const size_t o_src = 0, o_dst = pad256(src_bytes + 32), o_ws = o_dst + pad256(dst_cap + 32);
+    if (!ws->reserve_io(o_ws + scratch + 256)) return PQD_ERR_DEVICE;
+    uint8_t* d_io = static_cast<uint8_t*>(ws->d_io);
+    uint8_t* h_io = static_cast<uint8_t*>(ws->h_io);
+    if (src_bytes) {
+        std::memcpy(h_io + o_src, src, src_bytes);
+        PQD_HIP(hipMemcpyAsync(d_io + o_src, h_io + o_src, src_bytes, hipMemcpyHostToDevice, ws->stream));
+    }
+    p.src = d_io + o_src;
+    p.dst = d_io + o_dst;
+    int rc = pqd_encode_batch(ctx, &p, 1, d_io + o_ws, scratch + 256, ws->stream);
+    if (rc != PQD_OK) return rc;
+    if (status_arg) *status_arg = p.status_arg;
+    if (p.status == PQD_OK && p.out_bytes) {
+        PQD_HIP(hipMemcpyAsync(h_io + o_dst, d_io + o_dst, p.out_bytes, hipMemcpyDeviceToHost, ws->stream));
+        PQD_HIP(hipStreamSynchronize(ws->stream));
+        std::memcpy(dst, h_io + o_dst, p.out_bytes);
+    }
+    if (out_bytes) *out_bytes = p.status == PQD_OK ? p.out_bytes : 0;
+    return p.status;
+}
+
 int pqd_can_decode_in_place(int encoding) {
     return encoding == PQD_ENC_PLAIN || encoding == PQD_ENC_DELTA_LENGTH_BYTE_ARRAY;
 }

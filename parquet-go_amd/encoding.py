@@ -22,7 +22,7 @@ from typing import List, Optional, Tuple
 
 import numpy as np
 
-from ._lib import ENC, STATUS, Context, lib, status_name
+from ._lib import ENC, KIND, STATUS, Context, lib, status_name
 
 
 class EncodingError(Exception):
@@ -218,6 +218,57 @@ class Encoding:
             raise err
         return values, offs
 
+    # -- the Encode methods (encoding/encoding.go:29-41): dst is replaced, not appended to, as in the reference --
+    def _encode(self, kind: int, dtype, src, size: int = 0) -> bytes:
+        """One page through pqd_encode_values; the output buffer grows when the library asks (Go's append)."""
+        L = lib()
+        v = np.ascontiguousarray(src, dtype=dtype).reshape(-1)
+        n = v.size // size if size else v.size
+        if size and v.size % size:
+            raise ErrInvalidArgument(self.NAME, STATUS.INVALID_ARGUMENT, v.size, f"cannot encode FIXED_LEN_BYTE_ARRAY from input of size {v.size}: invalid argument")
+        cap = max(64, int(L.pqd_encode_bound(self.CODE, kind, size, n)))
+        nbytes, arg = C.c_uint64(0), C.c_int64(0)
+        for _ in range(3):
+            out = np.empty(cap, np.uint8)
+            rc = L.pqd_encode_values(self.ctx().handle, self.CODE, kind, size, _ptr(v), n, _ptr(out), out.size, C.byref(nbytes), C.byref(arg))
+            if rc == STATUS.DST_TOO_SMALL and arg.value > cap:
+                cap = arg.value
+                continue
+            break
+        if rc != STATUS.OK:
+            raise _error(self.NAME, rc, arg.value)
+        return out[: nbytes.value].tobytes()
+
+    def EncodeInt32(self, dst, src):
+        self._unsupported("INT32")
+
+    def EncodeInt64(self, dst, src):
+        self._unsupported("INT64")
+
+    def EncodeFloat(self, dst, src):
+        self._unsupported("FLOAT")
+
+    def EncodeDouble(self, dst, src):
+        self._unsupported("DOUBLE")
+
+    def EncodeFixedLenByteArray(self, dst, src, size: int):
+        self._unsupported("FIXED_LEN_BYTE_ARRAY")
+
+    def _enc_int32(self, dst, src):
+        return self._encode(KIND.INT32, np.int32, src)
+
+    def _enc_int64(self, dst, src):
+        return self._encode(KIND.INT64, np.int64, src)
+
+    def _enc_float(self, dst, src):
+        return self._encode(KIND.FLOAT, np.float32, src)
+
+    def _enc_double(self, dst, src):
+        return self._encode(KIND.DOUBLE, np.float64, src)
+
+    def _enc_flba(self, dst, src, size):
+        return self._encode(KIND.FIXED_LEN_BYTE_ARRAY, np.uint8, src, int(size))
+
     def _estimate(self, src) -> int:
         s = _bytes(src)
         return int(lib().pqd_estimate_decode_byte_array_size(self.ctx().handle, self.CODE, _ptr(s), s.size))
@@ -249,6 +300,7 @@ class RLEDictionary(Encoding):
     """rle.DictionaryEncoding (encoding/rle/dictionary.go:11-59): the bit width is the page's first byte."""
     NAME, CODE = "RLE_DICTIONARY", ENC.RLE_DICTIONARY
     DecodeInt32 = Encoding._int32
+    EncodeInt32 = Encoding._enc_int32
 
 
 class PlainDictionary(Encoding):
@@ -270,6 +322,8 @@ class DeltaBinaryPacked(Encoding):
     NAME, CODE = "DELTA_BINARY_PACKED", ENC.DELTA_BINARY_PACKED
     DecodeInt32 = Encoding._int32
     DecodeInt64 = Encoding._int64
+    EncodeInt32 = Encoding._enc_int32
+    EncodeInt64 = Encoding._enc_int64
 
 
 class DeltaLengthByteArray(Encoding):
@@ -295,6 +349,11 @@ class ByteStreamSplit(Encoding):
     DecodeFloat = Encoding._float
     DecodeDouble = Encoding._double
     DecodeFixedLenByteArray = Encoding._flba
+    EncodeInt32 = Encoding._enc_int32
+    EncodeInt64 = Encoding._enc_int64
+    EncodeFloat = Encoding._enc_float
+    EncodeDouble = Encoding._enc_double
+    EncodeFixedLenByteArray = Encoding._enc_flba
 
 
 def LookupEncoding(code: int) -> Encoding:

@@ -179,3 +179,38 @@ def decode_pages(ctx: Context, specs: List[PageSpec], device: int = 0, grow: boo
                 s2 = PageSpec(**{**s.__dict__, "offsets_cap": int(outs[i].arg)})
                 outs[i] = decode_pages(ctx, [s2], device, grow=True)[0]
     return outs
+
+
+def encode_pages(ctx: Context, jobs, device: int = 0, dst_slack: int = 0, misalign: int = 0, src_misalign: int = 0):
+    """Encodes pages in one batch through pqd_encode_batch.  `jobs` is a list of
+    (encoding, kind, values, bit_width) with `values` a numpy array; returns a list of
+    (status, status_arg, page bytes).  `dst_slack` < 0 makes every destination that many
+    bytes too small (to see the size the library asks for); `misalign` shifts the
+    destinations, `src_misalign` the values."""
+    from ._lib import EncodePage
+    L = lib()
+    torch = _torch()
+    pages, keep = [], []
+    for encoding, kind, values, bit_width in jobs:
+        v = np.ascontiguousarray(values)
+        n = v.size // bit_width if kind == 8 else v.size
+        src = to_device(v, device, src_misalign)
+        cap = max(0, int(L.pqd_encode_bound(encoding, kind, bit_width, n)) + dst_slack)
+        dst = DeviceBuffer(cap, device, misalign, fill=0xA5)
+        p = EncodePage()
+        p.src, p.n_values, p.dst, p.dst_cap = src.ptr, n, dst.ptr, cap
+        p.encoding, p.kind, p.bit_width = encoding, kind, bit_width
+        pages.append(p)
+        keep.append((src, dst))
+    arr = (EncodePage * max(len(pages), 1))(*pages)
+    ws_bytes = int(L.pqd_encode_workspace_size(arr, len(pages)))
+    ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=f"cuda:{device}")
+    stream = torch.cuda.current_stream(device).cuda_stream
+    rc = L.pqd_encode_batch(ctx.handle, arr, len(pages), ws.data_ptr(), ws.numel(), stream)
+    if rc != STATUS.OK:
+        raise PqdError(rc, 0, "pqd_encode_batch")
+    out = []
+    for i, (src, dst) in enumerate(keep):
+        raw = dst.numpy()
+        out.append((arr[i].status, arr[i].status_arg, raw[: arr[i].out_bytes].tobytes(), raw))
+    return out
