@@ -120,3 +120,25 @@ func estimateDecodeByteArraySize(e encoding.Encoding, ctx *Context, src []byte) 
 func canDecodeInPlace(e encoding.Encoding) bool {
 	return C.pqd_can_decode_in_place(C.int(e.Encoding())) != 0
 }
+
+// encodeValues renders the Encode methods (encoding/encoding.go:29-41): the values are encoded on
+// the GPU into dst's capacity, byte for byte what the reference's encoder writes, and dst is grown
+// when the library asks for more room (the reference appends, encoding/delta/binary_packed.go:77-91).
+// width is the FIXED_LEN_BYTE_ARRAY length, 0 otherwise; n counts values.
+func encodeValues(e encoding.Encoding, ctx *Context, kind, width int, dst []byte, src unsafe.Pointer, n int) ([]byte, error) {
+	dst = dst[:cap(dst)]
+	if bound := int(C.pqd_encode_bound(C.int(e.Encoding()), C.int(kind), C.int(width), C.uint64_t(n))); len(dst) < bound {
+		dst = make([]byte, bound)
+	}
+	for attempt := 0; ; attempt++ {
+		var outBytes C.uint64_t
+		var statusArg C.int64_t
+		st := C.pqd_encode_values(ctx.handle(), C.int(e.Encoding()), C.int(kind), C.int(width), src, C.uint64_t(n),
+			(*C.uint8_t)(unsafe.Pointer(unsafe.SliceData(dst))), C.uint64_t(len(dst)), &outBytes, &statusArg)
+		if st == C.PQD_ERR_DST_TOO_SMALL && attempt < 3 && int64(statusArg) > int64(len(dst)) {
+			dst = make([]byte, int64(statusArg))
+			continue
+		}
+		return dst[:outBytes], goError(e, st, int64(statusArg))
+	}
+}

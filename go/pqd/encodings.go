@@ -1,6 +1,8 @@
 package pqd
 
 import (
+	"unsafe"
+
 	"github.com/parquet-go/parquet-go/deprecated"
 	"github.com/parquet-go/parquet-go/encoding"
 	"github.com/parquet-go/parquet-go/format"
@@ -9,9 +11,10 @@ import (
 // The nine codecs of the reference's `encodings` table (encoding.go:50-60).  Like the reference's
 // codec types (encoding/plain/plain.go:24-26, encoding/rle/rle.go:30-33, ...) each embeds
 // encoding.NotSupported, which answers every method the codec does not define with
-// encoding.ErrNotSupported (encoding/notsupported.go:116-205); the Encode methods are among
-// those: a fork that writes files as well embeds the reference's CPU codec instead (see
-// patches/encodings.diff).  The zero value is ready to use and decodes on the Default context;
+// encoding.ErrNotSupported (encoding/notsupported.go:116-205).  DeltaBinaryPacked, RLEDictionary
+// and ByteStreamSplit also encode on the GPU; the other Encode methods are left to
+// encoding.NotSupported, and patches/encodings.diff pairs every codec with the reference's CPU
+// encoder.  The zero value is ready to use and decodes on the Default context;
 // set Context to pin a codec to another GPU.
 
 // Plain stands in for plain.Encoding (encoding/plain/plain.go:24-112).
@@ -113,6 +116,12 @@ func (e *RLEDictionary) DecodeInt32(dst []int32, src []byte) ([]int32, error) {
 	return decodeFixed(e, e.Context, kindInt32, 0, dst, src)
 }
 
+// EncodeInt32 writes the bit width of the widest index and the RLE / bit-packed hybrid of the
+// indexes (encoding/rle/dictionary.go:23-28, 52-59).
+func (e *RLEDictionary) EncodeInt32(dst []byte, src []int32) ([]byte, error) {
+	return encodeValues(e, e.Context, kindInt32, 0, dst, unsafe.Pointer(unsafe.SliceData(src)), len(src))
+}
+
 // BitPacked stands in for bitpacked.Encoding (encoding/bitpacked/bitpacked.go:8-33).
 type BitPacked struct {
 	encoding.NotSupported
@@ -142,6 +151,16 @@ func (e *DeltaBinaryPacked) DecodeInt32(dst []int32, src []byte) ([]int32, error
 
 func (e *DeltaBinaryPacked) DecodeInt64(dst []int64, src []byte) ([]int64, error) {
 	return decodeFixed(e, e.Context, kindInt64, 0, dst, src)
+}
+
+// EncodeInt32 and EncodeInt64 write blocks of 128 values in four miniblocks
+// (encoding/delta/binary_packed.go:26-34, 77-277).
+func (e *DeltaBinaryPacked) EncodeInt32(dst []byte, src []int32) ([]byte, error) {
+	return encodeValues(e, e.Context, kindInt32, 0, dst, unsafe.Pointer(unsafe.SliceData(src)), len(src))
+}
+
+func (e *DeltaBinaryPacked) EncodeInt64(dst []byte, src []int64) ([]byte, error) {
+	return encodeValues(e, e.Context, kindInt64, 0, dst, unsafe.Pointer(unsafe.SliceData(src)), len(src))
 }
 
 // DeltaLengthByteArray stands in for delta.LengthByteArrayEncoding
@@ -213,6 +232,34 @@ func (e *ByteStreamSplit) DecodeDouble(dst []float64, src []byte) ([]float64, er
 
 func (e *ByteStreamSplit) DecodeFixedLenByteArray(dst []byte, src []byte, size int) ([]byte, error) {
 	return decodeFixed(e, e.Context, kindFixedLenByteArray, size, dst, src)
+}
+
+// The Encode methods scatter byte k of every value to stream k
+// (encoding/bytestreamsplit/bytestreamsplit.go:19-33, bytestreamsplit_amd64.s:56-208).
+func (e *ByteStreamSplit) EncodeInt32(dst []byte, src []int32) ([]byte, error) {
+	return encodeValues(e, e.Context, kindInt32, 0, dst, unsafe.Pointer(unsafe.SliceData(src)), len(src))
+}
+
+func (e *ByteStreamSplit) EncodeInt64(dst []byte, src []int64) ([]byte, error) {
+	return encodeValues(e, e.Context, kindInt64, 0, dst, unsafe.Pointer(unsafe.SliceData(src)), len(src))
+}
+
+func (e *ByteStreamSplit) EncodeFloat(dst []byte, src []float32) ([]byte, error) {
+	return encodeValues(e, e.Context, kindFloat, 0, dst, unsafe.Pointer(unsafe.SliceData(src)), len(src))
+}
+
+func (e *ByteStreamSplit) EncodeDouble(dst []byte, src []float64) ([]byte, error) {
+	return encodeValues(e, e.Context, kindDouble, 0, dst, unsafe.Pointer(unsafe.SliceData(src)), len(src))
+}
+
+func (e *ByteStreamSplit) EncodeFixedLenByteArray(dst []byte, src []byte, size int) ([]byte, error) {
+	if size <= 0 || size > encoding.MaxFixedLenByteArraySize {
+		return dst[:0], encoding.Error(e, encoding.ErrInvalidArgument)
+	}
+	if len(src)%size != 0 {
+		return dst[:0], encoding.ErrEncodeInvalidInputSize(e, "FIXED_LEN_BYTE_ARRAY", len(src))
+	}
+	return encodeValues(e, e.Context, kindFixedLenByteArray, size, dst, unsafe.Pointer(unsafe.SliceData(src)), len(src)/size)
 }
 
 // Encodings is the reference's `encodings` table (encoding.go:50-60) over the GPU codecs, indexed

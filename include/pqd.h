@@ -249,6 +249,21 @@ int pqd_encode_batch(pqd_ctx* ctx, pqd_encode_page* pages, uint64_t n_pages, voi
 int pqd_encode_values(pqd_ctx* ctx, int encoding, int kind, int bit_width, const void* src, uint64_t n_values,
                       uint8_t* dst, uint64_t dst_cap, uint64_t* out_bytes, int64_t* status_arg);
 
+/* Dictionary.Bounds (dictionary.go:71-72): the smallest and the largest of dict[indexes[i]], the
+ * min / max statistics of a dictionary-encoded page (dictionaryBoundsInt32 / Int64 / Float32 /
+ * Float64 / Uint32 / Uint64, dictionary_amd64.go:13-28, dictionary_amd64.s:8-575), with the
+ * comparisons of dictionary_purego.go:68-170: of values that compare equal the first stays, a NaN
+ * is only ever the answer when it is the first value.  `kind` is INT32, INT64, FLOAT or DOUBLE,
+ * `is_unsigned` selects the uint32 / uint64 dictionaries.  bounds_dev gets two values {min, max}
+ * (zeros when n = 0); status_dev two int64 {status, arg}: PQD_ERR_INDEX_OUT_OF_BOUNDS with the
+ * position of the first bad index (errno indexOutOfBounds).  workspace_dev: device scratch of
+ * PQD_BOUNDS_WORKSPACE_BYTES, 16-byte aligned.  All pointers are device pointers; the kernels are
+ * enqueued on `hip_stream`, nothing is allocated. */
+#define PQD_BOUNDS_WORKSPACE_BYTES (64u << 10)
+int pqd_dict_bounds_device(pqd_ctx* ctx, int32_t kind, int32_t is_unsigned, const void* dict_dev, uint64_t dict_len,
+                           const int32_t* indexes_dev, uint64_t n, void* bounds_dev, void* workspace_dev,
+                           uint64_t workspace_bytes, int64_t* status_dev, void* hip_stream);
+
 /* ---- definition and repetition levels, device-resident ------------------ */
 
 /*

@@ -141,6 +141,7 @@ SYMBOLS = {
     "pqd_encode_workspace_size": (_u64, [C.POINTER(EncodePage), _u64]),
     "pqd_encode_batch": (_int, [_vp, C.POINTER(EncodePage), _u64, _vp, _u64, _vp]),
     "pqd_encode_values": (_int, [_vp, _int, _int, _int, _vp, _u64, _vp, _u64, _pu64, _pi64]),
+    "pqd_dict_bounds_device": (_int, [_vp, C.c_int32, C.c_int32, _vp, _u64, _vp, _u64, _vp, _vp, _u64, _vp, _vp]),
     "pqd_levels_workspace_size": (_u64, [_u64]),
     "pqd_levels_count_equal_device": (_int, [_vp, _vp, _u64, C.c_uint8, _vp, _u64, _vp, _vp]),
     "pqd_optional_expand_device": (_int, [_vp, _vp, _u64, C.c_uint8, _vp, _u64, C.c_uint32, C.c_int32, _vp, _vp, _vp, _u64, _vp, _vp]),

@@ -333,6 +333,300 @@ __global__ __launch_bounds__(ET) void bss_encode_kernel(EncPage* __restrict__ pa
     if (lead) { pg.status = PQD_OK; pg.arg = 0; pg.out_bytes = bytes; }
 }
 
+
+// ------------------------------------------------------ RLE_DICTIONARY indexes --
+
+constexpr uint32_t RE_GROUPS = ET;            // groups of eight values per workgroup, one per thread
+constexpr uint32_t RE_NONE = 0xffffffffu;
+
+// Eight indexes of one group, and what encodeInt32 asks of a group (rle.go:203-249): whether
+// its values are all the same, and whether it begins a run.  A run of repeated values goes on
+// over whole groups of that one value; a bit-packed run goes on until a group of one value.
+struct Group {
+    uint32_t v[8];
+    bool same;
+};
+
+__device__ inline Group load_group(gptr<const uint32_t> src, uint64_t g) {
+    Group r;
+    const u32x4_a4 a = *(gptr<const u32x4_a4>)(src + 8 * g), b = *(gptr<const u32x4_a4>)(src + 8 * g + 4); // a Go []int32 is 4-byte aligned
+    r.v[0] = a.x; r.v[1] = a.y; r.v[2] = a.z; r.v[3] = a.w;
+    r.v[4] = b.x; r.v[5] = b.y; r.v[6] = b.z; r.v[7] = b.w;
+    r.same = a.y == a.x && a.z == a.x && a.w == a.x && b.x == a.x && b.y == a.x && b.z == a.x && b.w == a.x;
+    return r;
+}
+
+__device__ inline bool starts_run(const Group& cur, bool have_prev, const Group& prev) {
+    if (!have_prev) return true;
+    if (cur.same != prev.same) return true;
+    return cur.same && cur.v[0] != prev.v[0];
+}
+
+struct RleEncShared {
+    unsigned long long starts[ET / 64]; // per wavefront: lanes whose group begins a run
+    uint32_t wave_total[ET / 64];
+    uint32_t first;
+    uint64_t before;
+    // worst case per group: a 10-byte run header and 32 bytes of packed values; the width byte, the all-zero
+    // page's single header and seven one-value runs at the end; spare dwords for the flush
+    uint32_t stage[(RE_GROUPS * 42 + 11 + 7 * 14) / 4 + 4];
+};
+
+// Pass one: the OR of all indexes of a page (its bit width) and, per tile, the first group that begins a run.
+__global__ __launch_bounds__(ET) void rle_encode_scan_kernel(EncPage* __restrict__ pages, const uint32_t* __restrict__ items,
+                                                             const uint64_t* __restrict__ prefix, uint32_t n_pages) {
+    __shared__ uint32_t sh_first, sh_or;
+    const uint32_t p = page_of_tile(prefix, n_pages, blockIdx.x);
+    EncPage& pg = pages[items[p]];
+    const uint64_t tile = blockIdx.x - prefix[p];
+    gptr<const uint32_t> src = (gptr<const uint32_t>)pg.src;
+    const uint64_t n = pg.n_values, groups = n / 8;
+    const uint64_t g = tile * RE_GROUPS + threadIdx.x;
+    if (threadIdx.x == 0) { sh_first = RE_NONE; sh_or = 0; }
+    lds_sync();
+    uint32_t any = 0;
+    if (g < groups) {
+        const Group cur = load_group(src, g);
+        Group prev = cur;
+        if (g > 0) prev = load_group(src, g - 1);
+        if (starts_run(cur, g > 0, prev)) atomicMin(&sh_first, (uint32_t)g);
+#pragma unroll
+        for (int e = 0; e < 8; e++) any |= cur.v[e];
+    }
+    if (tile + 1 == pg.n_tiles && threadIdx.x < (n & 7)) any |= src[groups * 8 + threadIdx.x];
+    for (int o = 32; o > 0; o >>= 1) any |= __shfl_xor(any, o);
+    if ((threadIdx.x & 63) == 0 && any) atomicOr(&sh_or, any);
+    lds_sync();
+    if (threadIdx.x == 0) {
+        pg.first_start[tile] = sh_first;
+        if (sh_or) atomicOr(pg.or_word, sh_or);
+    }
+}
+
+// Pass two, one wavefront per page: for every tile, the first run start in a later tile (or the number of groups).
+__global__ __launch_bounds__(64) void rle_encode_next_kernel(EncPage* __restrict__ pages, const uint32_t* __restrict__ items) {
+    EncPage& pg = pages[items[blockIdx.x]];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t groups = pg.n_values / 8;
+    uint32_t carry = (uint32_t)groups; // first start after the tiles looked at so far
+    for (uint64_t hi = pg.n_tiles; hi > 0; hi -= std::min<uint64_t>(64, hi)) {
+        const uint32_t look = (uint32_t)std::min<uint64_t>(64, hi);
+        // lane l looks at tile hi - 1 - l: later tiles sit in lower lanes
+        const uint64_t t = hi - 1 - lane;
+        uint32_t mine = lane < look ? pg.first_start[t] : RE_NONE;
+        // exclusive running minimum over the lower lanes, carried in from the tiles behind
+        uint32_t incl = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= (uint32_t)o) incl = std::min(incl, up);
+        }
+        uint32_t excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = RE_NONE;
+        if (lane < look) pg.next_start[t] = std::min(excl, carry);
+        carry = std::min(carry, lane_u32(incl, 63));
+    }
+}
+
+// Pass three: the page bytes.  A thread encodes its group into the staging area: the header of the run that begins
+// there, the repeated value of a run of repeats, the eight packed fields of a group of a bit-packed run.
+__global__ __launch_bounds__(ET) void rle_encode_write_kernel(EncPage* __restrict__ pages, const uint32_t* __restrict__ items,
+                                                              const uint64_t* __restrict__ prefix, uint32_t n_pages,
+                                                              unsigned long long* __restrict__ state) {
+    __shared__ RleEncShared sh;
+    const uint32_t p = page_of_tile(prefix, n_pages, blockIdx.x);
+    EncPage& pg = pages[items[p]];
+    const uint64_t tile = blockIdx.x - prefix[p];
+    gptr<const uint32_t> src = (gptr<const uint32_t>)pg.src;
+    const uint64_t n = pg.n_values, groups = n / 8;
+    const uint64_t g = tile * RE_GROUPS + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t bw = bits_len64(*pg.or_word);  // rle/dictionary.go:52-59: the widest index
+    const uint32_t vb = (bw + 7) / 8;
+    const bool last_tile = tile + 1 == pg.n_tiles;
+
+    Group cur;
+    bool have = g < groups && bw > 0, start = false;
+    if (have) {
+        cur = load_group(src, g);
+        Group prev = cur;
+        if (g > 0) prev = load_group(src, g - 1);
+        start = starts_run(cur, g > 0, prev);
+    }
+    const unsigned long long mask = __ballot(start);
+    if (lane == 0) sh.starts[wave] = mask;
+    for (uint32_t i = threadIdx.x; i < sizeof(sh.stage) / 4; i += ET) sh.stage[i] = 0;
+    lds_sync();
+    // where the run that begins here ends: the next start in the tile, or the first one behind it
+    uint64_t run_groups = 0;
+    if (start) {
+        uint64_t next = pg.next_start[tile];
+        unsigned long long m = lane == 63 ? 0ull : mask & (~0ull << (lane + 1));
+        for (uint32_t w = wave; ; w++) {
+            if (m) { next = tile * RE_GROUPS + 64ull * w + (uint32_t)__builtin_ctzll(m); break; }
+            if (w + 1 >= ET / 64) break;
+            m = sh.starts[w + 1];
+        }
+        run_groups = next - g;
+    }
+    // bytes this group adds to the page
+    uint32_t hdr = 0, mine = 0;
+    if (have) {
+        if (start) hdr = uvarint_len(cur.same ? (8 * run_groups) << 1 : (run_groups << 1) | 1);
+        mine = hdr + (cur.same ? (start ? vb : 0u) : bw);
+    }
+    // the values behind the last whole group are runs of repeats of their own (rle.go:236-246); the
+    // last tile's first thread encodes them once the groups are placed
+    uint32_t incl = wave_inclusive_scan(mine);
+    if (lane == 63) sh.wave_total[wave] = incl;
+    lds_sync();
+    uint32_t off = incl - mine, groups_total = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < ET / 64; w++) {
+        if (w < wave) off += sh.wave_total[w];
+        groups_total += sh.wave_total[w];
+    }
+    // the head of the page: the width byte; a page of zeros is one header and no value (rle.go:204-207)
+    uint32_t head = 0;
+    if (tile == 0) head = 1 + (bw == 0 ? uvarint_len(n << 1) : 0);
+    uint32_t tail_bytes = 0;
+    if (last_tile && bw > 0) {
+        for (uint64_t i = groups * 8; i < n;) {
+            uint64_t j = i + 1;
+            while (j < n && src[j] == src[i]) j++;
+            tail_bytes += uvarint_len((j - i) << 1) + vb;
+            i = j;
+        }
+    }
+    const uint32_t total = head + groups_total + tail_bytes;
+    if (wave == 0) {
+        const uint64_t before = tile_prefix(state + pg.tile_base, tile, total, lane);
+        if (lane == 0) sh.before = before;
+    }
+    if (tile == 0 && threadIdx.x == 0) {
+        stage_or(sh.stage, 0, bw, 8);
+        if (bw == 0) stage_uvarint(sh.stage, 1, n << 1);
+    }
+    if (have) {
+        uint32_t o = head + off;
+        if (start) o += stage_uvarint(sh.stage, o, cur.same ? (8 * run_groups) << 1 : (run_groups << 1) | 1);
+        if (cur.same) {
+            if (start) stage_or(sh.stage, 8ull * o, cur.v[0], 8 * vb);
+        } else {
+#pragma unroll
+            for (uint32_t e = 0; e < 8; e++) stage_or(sh.stage, 8ull * o + (uint64_t)e * bw, cur.v[e], bw);
+        }
+    }
+    if (last_tile && bw > 0 && threadIdx.x == 0) {
+        uint32_t o = head + groups_total;
+        for (uint64_t i = groups * 8; i < n;) {
+            uint64_t j = i + 1;
+            while (j < n && src[j] == src[i]) j++;
+            o += stage_uvarint(sh.stage, o, (j - i) << 1);
+            stage_or(sh.stage, 8ull * o, src[i], 8 * vb);
+            o += vb;
+            i = j;
+        }
+    }
+    lds_sync();
+    const uint64_t before = sh.before;
+    if (before + total <= pg.dst_cap) stage_flush(as_global(pg.dst), before, sh.stage, total);
+    if (last_tile && threadIdx.x == 0) {
+        const uint64_t bytes = before + total;
+        pg.out_bytes = bytes <= pg.dst_cap ? bytes : 0;
+        pg.status = bytes <= pg.dst_cap ? PQD_OK : PQD_ERR_DST_TOO_SMALL;
+        pg.arg = bytes <= pg.dst_cap ? 0 : (int64_t)bytes;
+    }
+}
+
+// ------------------------------------------------------------- dictionaryBounds --
+
+// The smallest and the largest of dict[indexes[i]] with the comparisons of the reference's loop
+// (dictionary_purego.go:68-170): `value < min` and `value > max` against the first value, so of
+// values that compare equal (+0 and -0) the earliest stays, and a NaN is never taken unless it
+// is the very first value, in which case nothing ever replaces it.
+template <typename T>
+struct Bound {
+    T lo, hi;
+    uint64_t lo_at, hi_at; // positions of the values; ~0: none yet
+};
+
+template <typename T>
+__device__ inline void bound_take(Bound<T>& b, T v, uint64_t at) {
+    if (v != v) return; // NaN
+    if (b.lo_at == ~0ull || v < b.lo || (v == b.lo && at < b.lo_at)) { b.lo = v; b.lo_at = at; }
+    if (b.hi_at == ~0ull || v > b.hi || (v == b.hi && at < b.hi_at)) { b.hi = v; b.hi_at = at; }
+}
+
+template <typename T>
+__device__ inline void bound_merge(Bound<T>& b, const Bound<T>& o) {
+    if (o.lo_at != ~0ull && (b.lo_at == ~0ull || o.lo < b.lo || (o.lo == b.lo && o.lo_at < b.lo_at))) { b.lo = o.lo; b.lo_at = o.lo_at; }
+    if (o.hi_at != ~0ull && (b.hi_at == ~0ull || o.hi > b.hi || (o.hi == b.hi && o.hi_at < b.hi_at))) { b.hi = o.hi; b.hi_at = o.hi_at; }
+}
+
+template <typename T>
+__device__ inline Bound<T> bound_reduce_workgroup(Bound<T> b, Bound<T>* scratch) {
+    scratch[threadIdx.x] = b;
+    __syncthreads();
+    for (uint32_t s = ET / 2; s > 0; s >>= 1) {
+        if (threadIdx.x < s) {
+            Bound<T> mine = scratch[threadIdx.x];
+            bound_merge(mine, scratch[threadIdx.x + s]);
+            scratch[threadIdx.x] = mine;
+        }
+        __syncthreads();
+    }
+    return scratch[0];
+}
+
+template <typename T>
+__global__ __launch_bounds__(ET) void dict_bounds_kernel(const T* __restrict__ dict, uint64_t dict_len,
+                                                         const int32_t* __restrict__ indexes, uint64_t n, Bound<T>* __restrict__ partial,
+                                                         unsigned long long* __restrict__ status) {
+    __shared__ Bound<T> scratch[ET];
+    Bound<T> b;
+    b.lo = b.hi = T(); b.lo_at = b.hi_at = ~0ull;
+    for (uint64_t i = (uint64_t)blockIdx.x * ET + threadIdx.x; i < n; i += (uint64_t)gridDim.x * ET) {
+        const uint32_t j = (uint32_t)indexes[i];
+        if ((uint64_t)j >= dict_len) { atomicMin(&status[1], (unsigned long long)i); continue; }
+        bound_take(b, dict[j], i);
+    }
+    b = bound_reduce_workgroup(b, scratch);
+    if (threadIdx.x == 0) partial[blockIdx.x] = b;
+}
+
+template <typename T>
+__global__ __launch_bounds__(ET) void dict_bounds_finish_kernel(const T* __restrict__ dict, uint64_t dict_len,
+                                                                const int32_t* __restrict__ indexes, uint64_t n,
+                                                                const Bound<T>* __restrict__ partial, uint32_t n_partial, T* __restrict__ out,
+                                                                unsigned long long* __restrict__ status) {
+    __shared__ Bound<T> scratch[ET];
+    Bound<T> b;
+    b.lo = b.hi = T(); b.lo_at = b.hi_at = ~0ull;
+    for (uint32_t i = threadIdx.x; i < n_partial; i += ET) bound_merge(b, partial[i]);
+    b = bound_reduce_workgroup(b, scratch);
+    if (threadIdx.x != 0) return;
+    if (status[1] != ~0ull) { // errno indexOutOfBounds (dictionary_amd64.s:213-215)
+        status[0] = PQD_ERR_INDEX_OUT_OF_BOUNDS;
+        out[0] = out[1] = T();
+        return;
+    }
+    status[0] = PQD_OK;
+    status[1] = 0;
+    T lo = T(), hi = T();
+    if (n > 0) {
+        const T first = dict[(uint32_t)indexes[0]];
+        if (first != first) lo = hi = first; // the comparisons never replace a NaN
+        else { lo = b.lo; hi = b.hi; }
+    }
+    out[0] = lo;
+    out[1] = hi;
+}
+
+__global__ void dict_bounds_init_kernel(unsigned long long* status) {
+    status[0] = 0;
+    status[1] = ~0ull;
+}
+
 } // namespace
 
 // The scratch an encode call needs, and where its parts lie.
@@ -342,6 +636,7 @@ struct EncodePlan {
     std::vector<uint64_t> fam_prefix[EF_N]; // per family: first tile of each of its pages, and the total
     uint64_t bss_max_values = 0;
     size_t o_pages = 0, o_items[EF_N] = {}, o_prefix[EF_N] = {}, o_state = 0, state_bytes = 0, upload_end = 0, total = 0;
+    size_t o_or = 0, o_first = 0, o_next = 0; // RLE_DICTIONARY: a word per page (inside the cleared block), two per tile
 };
 
 static int32_t value_width(int32_t kind, int32_t bit_width) {
@@ -358,6 +653,8 @@ static int32_t encode_family(int32_t encoding, int32_t kind, int32_t width) {
     switch (encoding) {
         case PQD_ENC_DELTA_BINARY_PACKED:
             return kind == PQD_KIND_INT32 ? EF_DELTA32 : kind == PQD_KIND_INT64 ? EF_DELTA64 : EF_NONE;
+        case PQD_ENC_RLE_DICTIONARY:
+            return kind == PQD_KIND_INT32 ? EF_RLE_DICT : EF_NONE;
         case PQD_ENC_BYTE_STREAM_SPLIT:
             if (kind == PQD_KIND_INT32 || kind == PQD_KIND_INT64 || kind == PQD_KIND_FLOAT || kind == PQD_KIND_DOUBLE) return EF_BSS;
             return kind == PQD_KIND_FIXED_LEN_BYTE_ARRAY && width > 0 && width <= 32767 ? EF_BSS : EF_NONE;
@@ -372,7 +669,7 @@ static size_t carve(size_t& off, size_t bytes) {
     return at;
 }
 
-static void plan_encode(const pqd_encode_page* in, uint64_t n, EncodePlan& plan) {
+static void plan_encode(const pqd_encode_page* in, uint64_t n, EncodePlan& plan, bool with_pointers) {
     plan.pages.resize(n);
     for (int f = 0; f < EF_N; f++) plan.fam_prefix[f].assign(1, 0);
     for (uint64_t i = 0; i < n; i++) {
@@ -386,16 +683,16 @@ static void plan_encode(const pqd_encode_page* in, uint64_t n, EncodePlan& plan)
         e.kind = in[i].kind;
         e.width = value_width(in[i].kind, in[i].bit_width);
         e.family = encode_family(e.encoding, e.kind, e.width);
-        if ((e.src == nullptr && e.n_values > 0) || (e.dst == nullptr && e.dst_cap > 0)) {
+        if (with_pointers && ((e.src == nullptr && e.n_values > 0) || (e.dst == nullptr && e.dst_cap > 0))) {
             e.family = EF_NONE;
             e.status = PQD_ERR_INVALID_ARGUMENT;
         } else if (e.family == EF_NONE) {
             e.status = PQD_ERR_NOT_SUPPORTED; // encoding.NotSupported answers these (encoding/notsupported.go:116-160)
-        } else if (e.family != EF_BSS && ((uintptr_t)e.src & (uintptr_t)(e.width - 1)) != 0) {
+        } else if (with_pointers && e.family != EF_BSS && ((uintptr_t)e.src & (uintptr_t)(e.width - 1)) != 0) {
             e.family = EF_NONE;
             e.status = PQD_ERR_INVALID_ARGUMENT; // typed values are aligned to their width, as a Go slice is
             e.arg = (int64_t)((uintptr_t)e.src & (uintptr_t)(e.width - 1));
-        } else if ((e.family == EF_DELTA32 || e.family == EF_DELTA64) && e.n_values > 0x7fffffffull) {
+        } else if (e.family != EF_BSS && e.n_values > 0x7fffffffull) {
             e.family = EF_NONE;
             e.status = PQD_ERR_INVALID_ARGUMENT; // the decoder refuses more values than MaxInt32 (binary_packed.go:447-449)
             e.arg = (int64_t)e.n_values;
@@ -404,6 +701,8 @@ static void plan_encode(const pqd_encode_page* in, uint64_t n, EncodePlan& plan)
         if (e.family == EF_DELTA32 || e.family == EF_DELTA64) {
             const uint64_t blocks = e.n_values < 2 ? 0 : (e.n_values - 1 + DE_BLOCK - 1) / DE_BLOCK;
             e.n_tiles = std::max<uint64_t>(1, (blocks + DE_TILE_BLOCKS - 1) / DE_TILE_BLOCKS);
+        } else if (e.family == EF_RLE_DICT) {
+            e.n_tiles = std::max<uint64_t>(1, (e.n_values / 8 + RE_GROUPS - 1) / RE_GROUPS);
         } else if (e.family == EF_BSS) {
             plan.bss_max_values = std::max(plan.bss_max_values, e.n_values);
         }
@@ -425,10 +724,40 @@ static void plan_encode(const pqd_encode_page* in, uint64_t n, EncodePlan& plan)
         plan.o_prefix[f] = carve(off, plan.fam_prefix[f].size() * sizeof(uint64_t));
     }
     plan.upload_end = off;
-    plan.state_bytes = tiles * sizeof(unsigned long long);
+    const size_t n_rle = plan.fam_items[EF_RLE_DICT].size(), rle_tiles = plan.fam_prefix[EF_RLE_DICT].back();
+    plan.state_bytes = tiles * sizeof(unsigned long long) + n_rle * sizeof(uint32_t);
     plan.o_state = carve(off, plan.state_bytes);
+    plan.o_or = plan.o_state + tiles * sizeof(unsigned long long);
+    plan.o_first = carve(off, rle_tiles * sizeof(uint32_t));
+    plan.o_next = carve(off, rle_tiles * sizeof(uint32_t));
     plan.total = off;
 }
+
+// Device addresses of the per-page scratch, once the workspace is known.
+static void place_scratch(EncodePlan& plan, uint8_t* ws) {
+    for (size_t k = 0; k < plan.fam_items[EF_RLE_DICT].size(); k++) {
+        EncPage& e = plan.pages[plan.fam_items[EF_RLE_DICT][k]];
+        e.or_word = reinterpret_cast<uint32_t*>(ws + plan.o_or) + k;
+        e.first_start = reinterpret_cast<uint32_t*>(ws + plan.o_first) + plan.fam_prefix[EF_RLE_DICT][k];
+        e.next_start = reinterpret_cast<uint32_t*>(ws + plan.o_next) + plan.fam_prefix[EF_RLE_DICT][k];
+    }
+}
+
+namespace {
+
+template <typename T>
+int run_bounds(const void* dict, uint64_t dict_len, const int32_t* indexes, uint64_t n, void* out, void* ws, unsigned long long* status,
+               hipStream_t s) {
+    Bound<T>* partial = static_cast<Bound<T>*>(ws);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (n + ET * 8 - 1) / (ET * 8)), PQD_BOUNDS_WORKSPACE_BYTES / sizeof(Bound<T>));
+    hipLaunchKernelGGL(dict_bounds_init_kernel, dim3(1), dim3(1), 0, s, status);
+    hipLaunchKernelGGL(dict_bounds_kernel<T>, dim3(grid), dim3(ET), 0, s, static_cast<const T*>(dict), dict_len, indexes, n, partial, status);
+    hipLaunchKernelGGL(dict_bounds_finish_kernel<T>, dim3(1), dim3(ET), 0, s, static_cast<const T*>(dict), dict_len, indexes, n, partial, grid,
+                       static_cast<T*>(out), status);
+    return hipGetLastError() == hipSuccess ? PQD_OK : PQD_ERR_DEVICE;
+}
+
+} // namespace
 
 } // namespace pqd
 
@@ -444,6 +773,10 @@ uint64_t pqd_encode_bound(int encoding, int kind, int bit_width, uint64_t n_valu
             const uint64_t blocks = n_values < 2 ? 0 : (n_values - 1 + DE_BLOCK - 1) / DE_BLOCK;
             return 24 + blocks * (14 + (uint64_t)DE_BLOCK * (kind == PQD_KIND_INT64 ? 8 : 4));
         }
+        case PQD_ENC_RLE_DICTIONARY:
+            // the width byte; per group of eight at most a 5-byte run header and 32 bytes of packed values;
+            // up to seven one-value runs at the end
+            return kind == PQD_KIND_INT32 ? 16 + (n_values / 8) * 37 + 7 * 6 : 0;
         case PQD_ENC_BYTE_STREAM_SPLIT:
             return n_values * (uint64_t)(width > 0 ? width : 0);
         default:
@@ -454,7 +787,7 @@ uint64_t pqd_encode_bound(int encoding, int kind, int bit_width, uint64_t n_valu
 uint64_t pqd_encode_workspace_size(const pqd_encode_page* pages, uint64_t n_pages) {
     if (pages == nullptr && n_pages > 0) return 0;
     EncodePlan plan;
-    plan_encode(pages, n_pages, plan);
+    plan_encode(pages, n_pages, plan, false);
     return plan.total + 256;
 }
 
@@ -465,10 +798,11 @@ int pqd_encode_batch(pqd_ctx* ctx, pqd_encode_page* pages, uint64_t n_pages, voi
     if (!guard.ok) return PQD_ERR_DEVICE;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     EncodePlan plan;
-    plan_encode(pages, n_pages, plan);
+    plan_encode(pages, n_pages, plan, true);
     uint8_t* ws = reinterpret_cast<uint8_t*>(((uintptr_t)workspace_dev + 255) & ~(uintptr_t)255);
     if (workspace_dev == nullptr || (uint64_t)(ws - static_cast<uint8_t*>(workspace_dev)) + plan.total > workspace_bytes)
         return PQD_ERR_DST_TOO_SMALL;
+    place_scratch(plan, ws);
     std::vector<uint8_t> image(plan.upload_end, 0);
     std::memcpy(image.data() + plan.o_pages, plan.pages.data(), n_pages * sizeof(EncPage));
     for (int f = 0; f < EF_N; f++) {
@@ -492,6 +826,14 @@ int pqd_encode_batch(pqd_ctx* ctx, pqd_encode_page* pages, uint64_t n_pages, voi
         else
             hipLaunchKernelGGL(delta_encode_kernel<int64_t>, dim3((uint32_t)tiles), dim3(ET), 0, s, d_pages, items_of(f), prefix_of(f), np, d_state);
     }
+    if (const uint64_t tiles = plan.fam_prefix[EF_RLE_DICT].back()) {
+        if (tiles > 0x7fffffffull) return PQD_ERR_INVALID_ARGUMENT;
+        const int f = EF_RLE_DICT;
+        const uint32_t np = (uint32_t)plan.fam_items[f].size();
+        hipLaunchKernelGGL(rle_encode_scan_kernel, dim3((uint32_t)tiles), dim3(ET), 0, s, d_pages, items_of(f), prefix_of(f), np);
+        hipLaunchKernelGGL(rle_encode_next_kernel, dim3(np), dim3(64), 0, s, d_pages, items_of(f));
+        hipLaunchKernelGGL(rle_encode_write_kernel, dim3((uint32_t)tiles), dim3(ET), 0, s, d_pages, items_of(f), prefix_of(f), np, d_state);
+    }
     if (!plan.fam_items[EF_BSS].empty()) {
         const uint64_t per = (uint64_t)ET * 4;
         const uint32_t gy = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (plan.bss_max_values + per - 1) / per), 1024);
@@ -508,6 +850,32 @@ int pqd_encode_batch(pqd_ctx* ctx, pqd_encode_page* pages, uint64_t n_pages, voi
         pages[i].out_bytes = out[i].status == PQD_OK ? out[i].out_bytes : 0;
     }
     return PQD_OK;
+}
+
+int pqd_dict_bounds_device(pqd_ctx* ctx, int32_t kind, int32_t is_unsigned, const void* dict_dev, uint64_t dict_len,
+                           const int32_t* indexes_dev, uint64_t n, void* bounds_dev, void* workspace_dev, uint64_t workspace_bytes,
+                           int64_t* status_dev, void* hip_stream) {
+    if (ctx == nullptr || bounds_dev == nullptr || status_dev == nullptr || workspace_dev == nullptr ||
+        workspace_bytes < PQD_BOUNDS_WORKSPACE_BYTES || ((uintptr_t)workspace_dev & 15) != 0 || (indexes_dev == nullptr && n > 0))
+        return PQD_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return PQD_ERR_DEVICE;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    unsigned long long* st = reinterpret_cast<unsigned long long*>(status_dev);
+    switch (kind) {
+        case PQD_KIND_INT32:
+            return is_unsigned ? run_bounds<uint32_t>(dict_dev, dict_len, indexes_dev, n, bounds_dev, workspace_dev, st, s)
+                               : run_bounds<int32_t>(dict_dev, dict_len, indexes_dev, n, bounds_dev, workspace_dev, st, s);
+        case PQD_KIND_INT64:
+            return is_unsigned ? run_bounds<uint64_t>(dict_dev, dict_len, indexes_dev, n, bounds_dev, workspace_dev, st, s)
+                               : run_bounds<int64_t>(dict_dev, dict_len, indexes_dev, n, bounds_dev, workspace_dev, st, s);
+        case PQD_KIND_FLOAT:
+            return run_bounds<float>(dict_dev, dict_len, indexes_dev, n, bounds_dev, workspace_dev, st, s);
+        case PQD_KIND_DOUBLE:
+            return run_bounds<double>(dict_dev, dict_len, indexes_dev, n, bounds_dev, workspace_dev, st, s);
+        default:
+            return PQD_ERR_NOT_SUPPORTED;
+    }
 }
 
 } // extern "C"

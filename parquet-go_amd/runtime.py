@@ -214,3 +214,26 @@ def encode_pages(ctx: Context, jobs, device: int = 0, dst_slack: int = 0, misali
         raw = dst.numpy()
         out.append((arr[i].status, arr[i].status_arg, raw[: arr[i].out_bytes].tobytes(), raw))
     return out
+
+
+def dict_bounds(ctx: Context, dictionary: np.ndarray, indexes, unsigned: bool = False, device: int = 0):
+    """Dictionary.Bounds on the device (pqd_dict_bounds_device): (status, arg, min, max) of
+    dictionary[indexes] for int32 / int64 / float32 / float64 (or uint32 / uint64) dictionaries."""
+    torch = _torch()
+    L = lib()
+    d = np.ascontiguousarray(dictionary)
+    kind = {"i4": KIND.INT32, "u4": KIND.INT32, "i8": KIND.INT64, "u8": KIND.INT64, "f4": KIND.FLOAT, "f8": KIND.DOUBLE}[d.dtype.str[1:]]
+    idx = np.ascontiguousarray(indexes, dtype=np.int32)
+    d_dev, i_dev = to_device(d, device), to_device(idx, device)
+    out = DeviceBuffer(2 * d.dtype.itemsize, device, fill=0xA5)
+    status = DeviceBuffer(16, device, fill=0xA5)
+    ws = torch.empty(64 << 10, dtype=torch.uint8, device=f"cuda:{device}")
+    stream = torch.cuda.current_stream(device).cuda_stream
+    rc = L.pqd_dict_bounds_device(ctx.handle, kind, int(unsigned or d.dtype.kind == "u"), d_dev.ptr, d.size, i_dev.ptr, idx.size,
+                                  out.ptr, ws.data_ptr(), ws.numel(), status.ptr, stream)
+    if rc != STATUS.OK:
+        raise PqdError(rc, 0, "pqd_dict_bounds_device")
+    torch.cuda.synchronize(device)
+    st = status.numpy().view(np.int64)
+    lo, hi = out.numpy().view(d.dtype)
+    return int(st[0]), int(st[1]), lo, hi

@@ -133,7 +133,7 @@ def test_every_c_call_matches_a_prototype():
     for name in ("pqd_ctx_create", "pqd_ctx_destroy", "pqd_abi_version", "pqd_status_name", "pqd_decode_levels", "pqd_decode_boolean",
                  "pqd_decode_int32", "pqd_decode_int64", "pqd_decode_int96", "pqd_decode_float", "pqd_decode_double",
                  "pqd_decode_byte_array", "pqd_decode_fixed_len_byte_array", "pqd_estimate_decode_byte_array_size",
-                 "pqd_can_decode_in_place", "pqd_dict_create", "pqd_dict_destroy", "pqd_dict_lookup", "pqd_batch_create",
+                 "pqd_can_decode_in_place", "pqd_encode_values", "pqd_encode_bound", "pqd_dict_create", "pqd_dict_destroy", "pqd_dict_lookup", "pqd_batch_create",
                  "pqd_batch_launch", "pqd_batch_finish", "pqd_batch_destroy", "pqd_chunk_scan_pages", "pqd_chunk_plan_pages"):
         assert called.get(name), f"no Go binding calls {name}"
 
@@ -160,6 +160,7 @@ def test_constants_types_and_fields_exist():
         assert name in fields["part"]
 
 
+ENCODE_METHODS = ("EncodeInt32", "EncodeInt64", "EncodeFloat", "EncodeDouble", "EncodeFixedLenByteArray")
 DECODE_METHODS = ("DecodeLevels", "DecodeBoolean", "DecodeInt32", "DecodeInt64", "DecodeInt96", "DecodeFloat", "DecodeDouble",
                   "DecodeByteArray", "DecodeFixedLenByteArray", "EstimateDecodeByteArraySize")
 
@@ -181,6 +182,8 @@ def test_codecs_define_what_the_python_mirror_defines():
         cls = getattr(E, codec)
         py = {m for m in DECODE_METHODS if getattr(cls, m) is not getattr(E.Encoding, m)}
         assert go & set(DECODE_METHODS) == py, (codec, sorted(go), sorted(py))
+        py_enc = {m for m in ENCODE_METHODS if getattr(cls, m) is not getattr(E.Encoding, m)}
+        assert go & set(ENCODE_METHODS) == py_enc, (codec, sorted(go), sorted(py_enc))
         assert {"String", "Encoding"} <= go
         assert 'func (e *%s) String() string            { return "%s" }' % (codec, names[codec]) in raw or \
             re.search(r'func \(e \*%s\) String\(\) string\s*\{ return "%s" \}' % (codec, names[codec]), raw), codec

@@ -128,3 +128,94 @@ def test_unsupported_combinations_and_the_codec_objects():
         E.Plain().EncodeInt64(None, v64)
     with pytest.raises(E.ErrNotSupported):
         E.DeltaBinaryPacked().EncodeDouble(None, f)
+
+
+def _index_inputs(rng):
+    out = []
+    for n in (0, 1, 7, 8, 9, 15, 16, 17, 63, 64, 65, 2047, 2048, 2049, 2055, 2056, 4096, 50000, 300007):
+        out.append((f"random-n{n}", rng.integers(0, 1000, size=n, dtype=np.int32)))
+    out.append(("zeros", np.zeros(5000, np.int32)))                       # bit width 0: one header, no value
+    out.append(("zeros-tail", np.zeros(5003, np.int32)))
+    out.append(("one-value", np.full(4099, 77, np.int32)))                 # one run over many tiles, then a tail
+    out.append(("negative", np.array([-1, 5, 5, 5, 5, 5, 5, 5, 5] * 300, np.int32)))  # 32-bit fields
+    out.append(("width-1", rng.integers(0, 2, size=30011, dtype=np.int32)))
+    out.append(("width-31", rng.integers(0, 2**31 - 1, size=9000, dtype=np.int32)))
+    # runs of repeats and bit-packed stretches of every length, crossing the 256-group tiles
+    v = np.empty(0, np.int32)
+    while v.size < 200000:
+        k = int(rng.integers(1, 5000)) if rng.integers(0, 2) else int(rng.integers(1, 40))
+        part = np.full(k, rng.integers(0, 300), np.int32) if rng.integers(0, 2) else rng.integers(0, 300, size=k, dtype=np.int32)
+        v = np.concatenate([v, part])
+    out.append(("writer-like", v))
+    # neighbouring runs of repeats with different values, aligned to the groups of eight
+    out.append(("aligned-runs", np.repeat(rng.integers(0, 50, size=3000, dtype=np.int32), 8)))
+    out.append(("aligned-runs-16", np.repeat(rng.integers(0, 3, size=3000, dtype=np.int32), 16)))
+    # a group of one value inside a bit-packed stretch ends it (rle.go:478-492)
+    w = rng.integers(0, 9, size=8 * 1000, dtype=np.int32)
+    w[8 * 10: 8 * 11] = 4
+    w[8 * 500: 8 * 503] = 2
+    out.append(("broadcast-inside", w))
+    return out
+
+
+def test_rle_dictionary_index_pages_bytes():
+    P = pkg()
+    rng = np.random.default_rng(15)
+    cases = _index_inputs(rng)
+    for misalign in (0, 1):
+        outs = _encode([(P.ENC.RLE_DICTIONARY, P.KIND.INT32, v, 0) for _, v in cases], misalign=misalign, src_misalign=4 * misalign)
+        for (label, v), (status, arg, page, raw) in zip(cases, outs):
+            want = bytes(O.rle_dict_encode_int32(v))
+            assert status == 0, (label, status, arg)
+            assert page == want, (label, len(page), len(want), next((i for i, (a, b) in enumerate(zip(page, want)) if a != b), None))
+            assert (raw[len(page):] == 0xA5).all(), label
+    specs = [spec(P.ENC.RLE_DICTIONARY, P.KIND.INT32, page, dst_cap=max(v.nbytes, 8)) for (_, v), (_, _, page, _) in zip(cases, outs)]
+    for (label, v), out in zip(cases, decode(specs)):
+        assert out.status == 0 and np.array_equal(out.data.view(np.int32)[: v.size], v), label
+    from parquet_go_amd import encoding as E
+    v = cases[-4][1]
+    assert E.RLEDictionary().EncodeInt32(None, v) == bytes(O.rle_dict_encode_int32(v))
+    assert np.array_equal(E.RLEDictionary().DecodeInt32(None, E.RLEDictionary().EncodeInt32(None, v)), v)
+
+
+def _bounds(d, idx):
+    """dictionary_purego.go:68-170, as written."""
+    lo = hi = d[idx[0]]
+    for i in idx[1:]:
+        v = d[i]
+        if v < lo:
+            lo = v
+        if v > hi:
+            hi = v
+    return lo, hi
+
+
+def test_dictionary_bounds():
+    from parquet_go_amd.runtime import dict_bounds
+    P = pkg()
+    rng = np.random.default_rng(16)
+    for dtype in (np.int32, np.int64, np.uint32, np.uint64, np.float32, np.float64):
+        if np.dtype(dtype).kind == "f":
+            d = (rng.standard_normal(5000) * 1e6).astype(dtype)
+        else:
+            info = np.iinfo(dtype)
+            d = rng.integers(info.min, info.max, size=5000, dtype=dtype, endpoint=True)
+        for n in (1, 2, 100, 5000, 400001):
+            idx = rng.integers(0, d.size, size=n, dtype=np.int32)
+            st, arg, lo, hi = dict_bounds(ctx(), d, idx)
+            assert (st, arg) == (0, 0)
+            assert (lo, hi) == (d[idx].min(), d[idx].max()), (dtype, n)
+        st, arg, lo, hi = dict_bounds(ctx(), d, np.zeros(0, np.int32))
+        assert (st, lo, hi) == (0, 0, 0)
+        idx = rng.integers(0, d.size, size=70000, dtype=np.int32)
+        idx[[123, 60000]] = [d.size, -1]
+        st, arg, lo, hi = dict_bounds(ctx(), d, idx)
+        assert (st, arg) == (P.STATUS.INDEX_OUT_OF_BOUNDS, 123)
+    # NaN and signed zeros follow the comparisons of the reference's loop
+    for dtype in (np.float32, np.float64):
+        d = np.array([1.5, np.nan, -0.0, 0.0, -3.0, np.inf, -np.inf, 7.0], dtype)
+        for idx in ([0, 1, 4], [1, 0, 4], [2, 3], [3, 2], [3, 2, 2, 3], [1], [1, 1], [0, 5, 6, 1], [2, 3, 0], [7, 1, 1, 0, 4] * 5000, [1] + [4, 7] * 40000):
+            st, arg, lo, hi = dict_bounds(ctx(), d, np.array(idx, np.int32))
+            wlo, whi = _bounds(d, idx)
+            assert st == 0
+            assert np.array([lo, hi], dtype).tobytes() == np.array([wlo, whi], dtype).tobytes(), (dtype, idx[:6], lo, hi, wlo, whi)
