@@ -39,6 +39,7 @@ struct pqd_batch {
     void* arena = nullptr;
     size_t arena_bytes = 0;
     bool own_arena = true; // false: the arena belongs to a caller's workspace
+    bool plain_tiled = false; // PLAIN byte-array pages were given scratch for the many-workgroups-per-page kernels
     DevPage* d_items = nullptr;
     DevResult* d_results = nullptr;
     FamilyList fam[N_FAMILIES];
@@ -259,6 +260,10 @@ int pqd_ctx_create(int device, pqd_ctx** out) {
     ctx->dict_lds_max_bytes = lds_max != nullptr ? strtoull(lds_max, nullptr, 10) : LDS_DICT_DEFAULT_MAX_BYTES;
     const char* lds_cap = getenv("PQD_DICT_LDS_CAP_BYTES");
     ctx->dict_lds_cap_bytes = lds_cap != nullptr ? strtoull(lds_cap, nullptr, 10) : 0;
+    // PLAIN byte-array pages: one wavefront per page, or many workgroups per page when the batch has too few
+    // pages to fill the chip with wavefronts (PQD_PLAIN_TILED=0 / 1: never / always, for comparisons and tests)
+    const char* tiled = getenv("PQD_PLAIN_TILED");
+    ctx->plain_tiled = tiled != nullptr && (tiled[0] == '0' || tiled[0] == '1') ? tiled[0] - '0' : 2;
     // with this context's device current: where this GPU keeps the static workspace
     ctx->levels_scratch = nullptr;
     if (levels_scratch_address(&ctx->levels_scratch) != PQD_OK) ctx->levels_scratch = nullptr;
@@ -418,6 +423,26 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
             }
         }
         b->map[i] = m;
+    }
+
+    // ---- PLAIN byte arrays: a wavefront walks a page at about 0.3 GB/s, so a batch needs some 2000 pages to keep
+    // the chip busy that way; with few, long pages many workgroups take a page each (measured: 256 pages of 1.5 MB
+    // 1.39 ms -> 1.06 ms, 2048 pages of 190 KB 0.39 ms -> 1.1 ms) ----
+    {
+        size_t n_plain = 0;
+        uint64_t plain_bytes = 0;
+        for (const DevPage& d : b->items)
+            if (d.family == FAM_PLAIN_BYTE_ARRAY) { n_plain++; plain_bytes += d.src_len; }
+        const bool tiled = ctx->plain_tiled == 1 ||
+                           (ctx->plain_tiled == 2 && n_plain > 0 && n_plain <= (size_t)ctx->n_cus + ctx->n_cus / 4 && plain_bytes / n_plain >= (256u << 10));
+        b->plain_tiled = tiled;
+        if (tiled) {
+            for (DevPage& d : b->items) {
+                if (d.family != FAM_PLAIN_BYTE_ARRAY) continue;
+                d.lengths_cap = plain_bytes_scratch_words(d.src_len);
+                lengths_entries += d.lengths_cap;
+            }
+        }
     }
 
     // ---- dictionary pages with dense 4- or 8-byte values: through an LDS-resident dictionary when that pays ----
@@ -669,6 +694,10 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
             d.tile_run = reinterpret_cast<uint32_t*>(a + o_rle_tile_run) + d.lengths_cap;
             d.lengths_cap = 0;
         }
+        if (d.family == FAM_PLAIN_BYTE_ARRAY && d.lengths_cap > 0) {
+            d.lengths = lengths;
+            lengths += d.lengths_cap;
+        }
         if (d.family == FAM_DICT_BYTES) {
             DevPage& ix = b->items[d.chain];
             d.lengths = lengths;
@@ -773,7 +802,8 @@ int pqd_batch_launch(pqd_batch* b, void* hip_stream) {
     launch_bitpacked(b->d_items, b->d_results, b->fam[FAM_BITPACKED].dev, fam_n(FAM_BITPACKED), b->max_src[FAM_BITPACKED] * 8, s_flat);
     launch_bss(b->d_items, b->d_results, b->fam[FAM_BSS].dev, fam_n(FAM_BSS), b->max_src[FAM_BSS], s_flat);
     launch_plain_fixed(b->d_items, b->d_results, b->fam[FAM_PLAIN_FIXED].dev, fam_n(FAM_PLAIN_FIXED), b->max_src[FAM_PLAIN_FIXED], s_flat);
-    launch_plain_byte_array(b->d_items, b->d_results, b->fam[FAM_PLAIN_BYTE_ARRAY].dev, fam_n(FAM_PLAIN_BYTE_ARRAY), s_walk);
+    launch_plain_byte_array(b->d_items, b->d_results, b->fam[FAM_PLAIN_BYTE_ARRAY].dev, fam_n(FAM_PLAIN_BYTE_ARRAY),
+                            b->plain_tiled ? b->max_src[FAM_PLAIN_BYTE_ARRAY] : 0, s_walk);
     launch_dict_bytes(b->d_items, b->d_results, b->fam[FAM_DICT_BYTES].dev, fam_n(FAM_DICT_BYTES), b->dict_bytes_max_values, s_rle);
     launch_dlba(b->d_items, b->d_results, b->fam[FAM_DLBA].dev, fam_n(FAM_DLBA), b->max_src[FAM_DLBA], s);
     launch_dba(b->d_items, b->d_results, b->fam[FAM_DBA].dev, fam_n(FAM_DBA), b->dba_max_values, s);

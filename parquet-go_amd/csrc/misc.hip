@@ -304,6 +304,7 @@ __global__ __launch_bounds__(WT) void plain_byte_array_kernel(const DevPage* __r
     const uint32_t* stage32 = reinterpret_cast<const uint32_t*>(stage);
     const uint32_t item = items[blockIdx.x];
     const DevPage& pg = pages[item];
+    if (pg.lengths != nullptr) return; // a page with scratch is decoded by many workgroups (plain_bytes.hip)
     DevResult* res = &results[item];
     gptr<const uint8_t> src = as_global(pg.src);
     gptr<uint8_t> dst = as_global(pg.dst);
@@ -1166,8 +1167,8 @@ void launch_plain_fixed(const DevPage* pages, DevResult* results, const uint32_t
     hipLaunchKernelGGL(plain_fixed_kernel, dim3(n_items, tile_slots(max_bytes, MT * 64)), dim3(MT), 0, stream, pages, results, items);
 }
 
-void launch_plain_byte_array(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
-                             hipStream_t stream) {
+void launch_plain_byte_array_walk(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
+                                  hipStream_t stream) {
     if (n_items == 0) return;
     hipLaunchKernelGGL(plain_byte_array_kernel, dim3(n_items), dim3(WT), 0, stream, pages, results, items);
 }

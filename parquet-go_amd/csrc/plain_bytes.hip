@@ -1,0 +1,597 @@
+// plain_bytes.hip -- PLAIN byte arrays, many workgroups per page
+// (plain.Encoding.DecodeByteArray, encoding/plain/plain.go:76-94).
+//
+// A page is a chain of `u32 length | bytes` records: where a record starts is only known once the
+// record before it has been read.  The decoded values are the page with the length fields taken
+// out, so byte q of record k goes to q - 4 (k + 1), and the offset of record k is its position
+// minus 4 k: all it takes is the chain of record positions and their ranks.
+//
+// The chain is found speculatively.  A page is cut into tiles of 16 KB, a tile into 256 sub-chunks
+// of 64 bytes, one per lane.  A lane guesses where the chain enters its sub-chunk -- the first
+// position from which three records in a row have lengths that fit the page -- and walks the
+// records that start in the sub-chunk.  A lane's walk ends at some position in a later
+// sub-chunk; when that is the later lane's guess the two walks link up.  Pointer doubling over
+// the 256 lanes then tells which lanes lie on the chain that starts at the tile's entry and how
+// many records precede each; where the chain arrives at a position a lane had not guessed, that
+// lane walks again from there and the doubling is redone.  Tiles are chained the same way: a
+// first kernel resolves every tile from its own guess, one wavefront per page checks that each
+// tile's guess is where the tile before it ended (walking a tile itself when it is not) and
+// hands every tile its true entry and rank, and a last kernel resolves the tiles again from the
+// true entries, writes the offsets and copies the bytes.  Wrong guesses cost time, never
+// correctness: every position used in the end was reached from the start of the page.
+#include <algorithm>
+
+#include "pqd_internal.h"
+
+namespace pqd {
+namespace {
+
+constexpr uint32_t PT = 256;            // threads per workgroup
+constexpr uint32_t PSUB = 64;           // bytes of the tile a lane walks
+constexpr uint32_t PTILE = PT * PSUB;   // bytes per tile
+constexpr uint32_t P_NONE = 0xffffffffu;
+constexpr uint32_t PLOOK = 256;         // bytes staged behind the tile: a length field may straddle its end, and the
+                                        // last lanes want to see the record after their first
+constexpr uint32_t PSTEPS = 6;          // records in a row that make a position a guess
+
+// per tile, words in the page's scratch
+enum : uint32_t { TW_GUESS = 0, TW_EXIT = 1, TW_COUNT = 2, TW_LAST = 3, TW_FLAGS = 4, TW_ENTRY = 5, TW_RANK = 6, TW_PREV = 7, TW_WORDS = 8 };
+// per page, words behind the tiles'
+enum : uint32_t { PW_STATUS = 0, PW_COUNT = 1, PW_END = 2, PW_DST_RANK = 3, PW_DST_OUT = 4, PW_DST_LEN = 5, PW_DST_POS = 6,
+                  PW_OFF_OUT = 7, PW_OFF_POS = 8, PW_WORDS = 16 };
+
+// how a tile's chain ends, and jump targets of the doubling beyond the lanes
+constexpr uint32_t T_END = 256, T_ERR = 257, T_BROKEN = 258, T_NONE = 259;
+
+typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+typedef uint32_t u32x3_a1 __attribute__((ext_vector_type(3), aligned(1)));
+
+struct PbShared {
+    alignas(16) uint32_t stage[(PTILE + PLOOK) / 4 + 16];
+    unsigned long long starts[PT];  // per byte of a lane's sub-chunk: a record starts here
+    unsigned long long headers[PT]; // ... the byte belongs to a length field
+    uint32_t exits[PT * 2];         // per byte of the tile: some lane's walk ended here
+    uint32_t guess[PT];             // tile position where a lane starts, or P_NONE
+    uint32_t exit_[PT];             // tile position where the lane's walk ended (the failing record's, when it failed)
+    uint16_t hop[8][PT];            // lane reached after 1, 2, 4 ... links (or T_*)
+    uint16_t before[PT];            // records of the tile that start before the sub-chunk
+    uint8_t err[PT];
+    uint8_t reach[PT];
+    uint32_t wave_sum[PT / 64];
+    uint32_t all_ok, first_guess, last_lane, term_lane, term_type, count, last_start;
+};
+
+__device__ inline void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// The page as a tile sees it; positions inside a tile are relative to its first byte.
+struct Tile {
+    gptr<const uint8_t> src;
+    uint64_t base;     // page position of the tile's first byte
+    uint32_t rem;      // bytes from there to the end of the page
+    uint32_t bytes;    // bytes of the tile inside the page
+    uint32_t staged;   // bytes in LDS (the tile and a little behind it)
+    bool narrow;       // the page is short enough for the top byte of every length to be zero
+};
+
+__device__ inline Tile make_tile(const DevPage& pg, uint64_t tile) {
+    Tile t;
+    t.src = as_global(pg.src);
+    t.base = tile * PTILE;
+    t.rem = (uint32_t)(pg.src_len - t.base);
+    t.bytes = std::min(PTILE, t.rem);
+    t.staged = std::min(PTILE + PLOOK, t.rem);
+    t.narrow = pg.src_len < (1u << 24);
+    return t;
+}
+
+__device__ inline void stage_tile(PbShared& sh, const Tile& t) {
+    // 16 bytes per lane and step; the page may start at any address
+    const uint32_t body = t.staged / 16;
+    for (uint32_t c = threadIdx.x; c < body; c += PT) {
+        const u32x4_a1 w = *(gptr<const u32x4_a1>)(t.src + t.base + (uint64_t)c * 16);
+        *reinterpret_cast<u32x4*>(&sh.stage[c * 4]) = w;
+    }
+    uint8_t* bytes = reinterpret_cast<uint8_t*>(sh.stage);
+    for (uint32_t k = body * 16 + threadIdx.x; k < t.staged; k += PT) bytes[k] = t.src[t.base + k];
+}
+
+// The length field at tile position p (p + 4 <= staged).
+__device__ inline uint32_t length_at(const PbShared& sh, uint32_t p) {
+    const uint32_t d = p >> 2;
+    return __builtin_amdgcn_alignbit(sh.stage[d + 1], sh.stage[d], (p & 3) * 8);
+}
+
+// plain.go:81-88: what a record at p (inside the page) must satisfy.
+__device__ inline bool record_fits(const PbShared& sh, const Tile& t, uint32_t p, uint32_t* len) {
+    if (t.rem - p < 4) return false;
+    *len = length_at(sh, p);
+    return *len <= t.rem - p - 4;
+}
+
+// How much a position looks like the start of a record: 0 not at all (a record there would not fit the page, or the
+// one after it, ... would not), 2 the record fits and so do those after it as far as they are staged (at least one
+// of them), 1 the record fits but the next one lies beyond the staged bytes.
+__device__ inline uint32_t looks_like_a_record(const PbShared& sh, const Tile& t, uint32_t p) {
+    uint32_t len;
+    if (!record_fits(sh, t, p, &len)) return 0;
+    p += 4 + len;
+    if (p == t.rem) return 2;            // the last record of the page
+    if (p + 4 > t.staged) return 1;
+    for (uint32_t s = 1; s < PSTEPS; s++) {
+        if (!record_fits(sh, t, p, &len)) return 0;
+        p += 4 + len;
+        if (p == t.rem || p + 4 > t.staged) break;
+    }
+    return 2;
+}
+
+// The records that start in the lane's sub-chunk, from tile position `from`.
+__device__ inline void walk_lane(PbShared& sh, const Tile& t, uint32_t lane, uint32_t from) {
+    const uint32_t end = std::min((lane + 1) * PSUB, t.bytes);
+    uint32_t p = from;
+    unsigned long long mask = 0;
+    bool failed = false;
+    while (p < end) {
+        uint32_t len;
+        if (!record_fits(sh, t, p, &len)) { failed = true; break; }
+        mask |= 1ull << (p - lane * PSUB);
+        p += 4 + len;
+    }
+    sh.starts[lane] = mask;
+    sh.err[lane] = failed ? 1 : 0;
+    sh.exit_[lane] = p;
+}
+
+// Per byte of the lane's 64 (+3): is it zero?  Branch-free, out of the staged dwords.
+__device__ inline void zero_bytes(const PbShared& sh, uint32_t lane, unsigned long long* lo, uint32_t* hi) {
+    unsigned long long z = 0;
+    uint32_t top = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < 17; i++) {
+        const uint32_t w = sh.stage[lane * (PSUB / 4) + i];
+        const uint32_t y = ~(((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w | 0x7f7f7f7fu); // 0x80 in every zero byte
+        const uint32_t nib = (((y >> 7) * 0x00204081u) >> 21) & 0xfu;
+        if (i < 16) z |= (unsigned long long)nib << (4 * i);
+        else top = nib;
+    }
+    *lo = z;
+    *hi = top;
+}
+
+// Where the lane's walk starts: the first position of its sub-chunk that looks like the start of a record, with
+// a record after it that looks like one too; failing that, a position whose record reaches past the staged bytes,
+// preferably the last of a row of candidates (the zero bytes of a length field make a row that ends at its start).
+__device__ inline uint32_t guess_lane(const PbShared& sh, const Tile& t, uint32_t lane) {
+    const uint32_t lo = lane * PSUB;
+    if (lo >= t.bytes) return P_NONE;
+    unsigned long long cand = ~0ull;
+    if (t.narrow) { // the fourth byte of a length field is zero
+        unsigned long long z;
+        uint32_t top;
+        zero_bytes(sh, lane, &z, &top);
+        cand = (z >> 3) | ((unsigned long long)top << 61);
+    }
+    if (t.bytes - lo < PSUB) cand &= (1ull << (t.bytes - lo)) - 1;
+    const unsigned long long row_ends = cand & ~(cand >> 1);
+    uint32_t weak = P_NONE, weak_end = P_NONE;
+    // the ends of rows first: with text for values the first of them is the record
+    for (unsigned long long m = row_ends; m; m &= m - 1) {
+        const uint32_t bit = (uint32_t)__builtin_ctzll(m);
+        const uint32_t how = looks_like_a_record(sh, t, lo + bit);
+        if (how == 2) return lo + bit;
+        if (how == 1 && weak_end == P_NONE) weak_end = lo + bit;
+    }
+    for (unsigned long long m = cand & ~row_ends; m; m &= m - 1) {
+        const uint32_t bit = (uint32_t)__builtin_ctzll(m);
+        const uint32_t how = looks_like_a_record(sh, t, lo + bit);
+        if (how == 2) return lo + bit;
+        if (how == 1 && weak == P_NONE) weak = lo + bit;
+    }
+    return weak_end != P_NONE ? weak_end : weak;
+}
+
+// Finds the chain of the tile that starts at tile position `entry` (P_NONE: at the first guess).
+// On return reach / starts / exit_ / err describe the lanes on the chain (starts is zero elsewhere),
+// term_lane and term_type its end, count its records, last_start the last of them.
+__device__ inline void resolve_tile(PbShared& sh, const Tile& t, uint32_t entry) {
+    const uint32_t lane = threadIdx.x;
+    if (lane == 0) { sh.first_guess = P_NONE; sh.all_ok = 1; sh.last_lane = 0; sh.count = 0; sh.last_start = 0; sh.term_type = T_NONE; sh.term_lane = 0; }
+    sh.exits[2 * lane] = 0;
+    sh.exits[2 * lane + 1] = 0;
+    lds_sync();
+    // ---- every lane guesses and walks ----
+    uint32_t g = P_NONE;
+    if (entry != P_NONE && entry / PSUB == lane) g = entry;
+    else if (entry == P_NONE || lane > entry / PSUB) g = guess_lane(sh, t, lane);
+    sh.guess[lane] = g;
+    sh.starts[lane] = 0; sh.err[lane] = 0; sh.exit_[lane] = 0;
+    if (g != P_NONE) {
+        walk_lane(sh, t, lane, g);
+        atomicMin(&sh.first_guess, g);
+        atomicMax(&sh.last_lane, lane);
+        const uint32_t x = sh.exit_[lane];
+        if (!sh.err[lane] && x < t.bytes) atomicOr(&sh.exits[x >> 5], 1u << (x & 31));
+    }
+    lds_sync();
+    const uint32_t start = entry != P_NONE ? entry : sh.first_guess;
+    if (start == P_NONE) { // no record starts in this tile as far as anyone can tell
+        sh.reach[lane] = 0;
+        lds_sync();
+        return;
+    }
+    // ---- the walks are the chain when every walk ends where another starts, and starts where another ends ----
+    if (g != P_NONE) {
+        const uint32_t x = sh.exit_[lane];
+        bool ok = true;
+        if (!sh.err[lane] && x < t.bytes) ok = (sh.starts[x / PSUB] >> (x % PSUB)) & 1;
+        else if (lane != sh.last_lane) ok = false;              // only the last walk may leave the tile or fail
+        if (g != start) ok = ok && ((sh.exits[g >> 5] >> (g & 31)) & 1);
+        if (!ok) sh.all_ok = 0;
+    }
+    lds_sync();
+    if (sh.all_ok) {
+        sh.reach[lane] = g != P_NONE ? 1 : 0;
+        if (lane == 0) { sh.term_lane = sh.last_lane; sh.term_type = sh.err[sh.last_lane] ? T_ERR : T_END; }
+    } else {
+        // ---- some guess was wrong: follow the links from the entry, pointer doubling over the lanes ----
+        const uint32_t lane0 = start / PSUB;
+        for (uint32_t round = 0; round <= PT; round++) {
+            uint32_t hop = T_NONE;
+            if (sh.guess[lane] != P_NONE) {
+                const uint32_t x = sh.exit_[lane];
+                if (sh.err[lane]) hop = T_ERR;
+                else if (x >= t.bytes) hop = T_END;
+                else hop = sh.guess[x / PSUB] == x ? x / PSUB : T_BROKEN;
+            }
+            sh.hop[0][lane] = (uint16_t)hop;
+            if (lane == 0) { sh.term_type = T_END; sh.term_lane = lane0; } // (always overwritten: a chain has one last lane)
+            sh.reach[lane] = lane == lane0 ? 1 : 0;
+            lds_sync();
+            for (uint32_t k = 1; k < 8; k++) {
+                const uint32_t a = sh.hop[k - 1][lane];
+                sh.hop[k][lane] = a < PT ? sh.hop[k - 1][a] : (uint16_t)a;
+                lds_sync();
+            }
+            // who is on the chain: the lanes 128, then 64, ... then 1 links from one already known
+            for (int k = 7; k >= 0; k--) {
+                const bool on = sh.reach[lane] != 0;
+                const uint32_t a = sh.hop[k][lane];
+                lds_sync();
+                if (on && a < PT) sh.reach[a] = 1;
+                lds_sync();
+            }
+            if (sh.reach[lane] && sh.hop[0][lane] >= PT) { sh.term_lane = lane; sh.term_type = sh.hop[0][lane]; }
+            lds_sync();
+            if (sh.term_type != T_BROKEN) break;
+            // the chain arrives somewhere nobody guessed: that lane walks from there, and the links are redone
+            const uint32_t x = sh.exit_[sh.term_lane];
+            lds_sync();
+            if (lane == x / PSUB) {
+                sh.guess[lane] = x;
+                walk_lane(sh, t, lane, x);
+            }
+            lds_sync();
+        }
+        if (!sh.reach[lane]) sh.starts[lane] = 0;
+    }
+    // ---- the records of the chain: how many, and the last ----
+    const unsigned long long mine = sh.reach[lane] ? sh.starts[lane] : 0;
+    if (mine) {
+        atomicAdd(&sh.count, (uint32_t)__builtin_popcountll(mine));
+        atomicMax(&sh.last_start, lane * PSUB + 63 - (uint32_t)__builtin_clzll(mine));
+    }
+    lds_sync();
+}
+
+// Pass one: every tile from its own guess.
+__global__ __launch_bounds__(PT) void plain_bytes_guess_kernel(const DevPage* __restrict__ pages, const uint32_t* __restrict__ items) {
+    __shared__ PbShared sh;
+    const DevPage& pg = pages[items[blockIdx.x]];
+    if (pg.lengths == nullptr) return; // left to the one-wavefront walker
+    const uint64_t tiles = (pg.src_len + PTILE - 1) / PTILE;
+    gptr<uint32_t> words = (gptr<uint32_t>)pg.lengths;
+    for (uint64_t tile = blockIdx.y; tile < tiles; tile += gridDim.y) {
+        const Tile t = make_tile(pg, tile);
+        lds_sync(); // the tile before is done with the shared memory
+        stage_tile(sh, t);
+        lds_sync();
+        resolve_tile(sh, t, tile == 0 ? 0u : P_NONE);
+        if (threadIdx.x == 0) {
+            gptr<uint32_t> w = words + tile * TW_WORDS;
+            const uint32_t type = sh.term_type;
+            if (type == T_NONE) {
+                w[TW_GUESS] = P_NONE; w[TW_EXIT] = 0; w[TW_COUNT] = 0; w[TW_LAST] = P_NONE; w[TW_FLAGS] = 0;
+            } else {
+                w[TW_GUESS] = (uint32_t)t.base + (tile == 0 ? 0u : sh.first_guess);
+                w[TW_EXIT] = (uint32_t)t.base + sh.exit_[sh.term_lane];
+                w[TW_COUNT] = sh.count;
+                w[TW_FLAGS] = type == T_ERR ? 1u : 0u;
+                w[TW_LAST] = sh.count ? (uint32_t)t.base + sh.last_start : P_NONE;
+            }
+        }
+    }
+}
+
+// Pass two, one wavefront per page: each tile's true entry, the records in front of it and the last record
+// before it; the page's record count, where its chain ends and how.  64 tiles at a time: when every tile's
+// guess is where the tiles before it ended, ranks and last records are prefix operations over the lanes;
+// otherwise the window is gone through tile by tile, and a tile that guessed wrong is walked record by record.
+__global__ __launch_bounds__(64) void plain_bytes_chain_kernel(const DevPage* __restrict__ pages, const uint32_t* __restrict__ items) {
+    const DevPage& pg = pages[items[blockIdx.x]];
+    if (pg.lengths == nullptr) return;
+    gptr<const uint8_t> src = as_global(pg.src);
+    const uint32_t n = (uint32_t)pg.src_len;
+    const uint32_t tiles = (n + PTILE - 1) / PTILE;
+    gptr<uint32_t> words = (gptr<uint32_t>)pg.lengths;
+    gptr<uint32_t> page = words + (uint64_t)tiles * TW_WORDS;
+    const uint32_t lane = threadIdx.x;
+    uint32_t e = 0;          // where the chain stands
+    uint32_t rank = 0, prev = P_NONE, status = 0;
+    for (uint32_t t0 = 0; t0 < tiles; t0 += 64) {
+        const uint32_t mine = t0 + lane;
+        const bool have = mine < tiles;
+        uint32_t g = P_NONE, x = 0, c = 0, last = P_NONE, fl = 0;
+        if (have) {
+            gptr<const uint32_t> w = words + (uint64_t)mine * TW_WORDS;
+            g = w[TW_GUESS]; x = w[TW_EXIT]; c = w[TW_COUNT]; last = w[TW_LAST]; fl = w[TW_FLAGS];
+        }
+        const uint32_t base = mine * PTILE, end = have ? std::min(base + PTILE, n) : 0;
+        uint32_t my_entry = P_NONE, my_rank = 0, my_prev = P_NONE;
+        // ---- all at once: where the chain stands in front of every tile if all guesses hold ----
+        bool done = false;
+        if (status == 0) {
+            // the exit of the nearest tile before this one that has records (exits only grow)
+            uint32_t ex = have && g != P_NONE ? x : 0;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(ex, o); if (lane >= (uint32_t)o) ex = std::max(ex, up); }
+            uint32_t in = __shfl_up(ex, 1);
+            if (lane == 0) in = 0;
+            in = std::max(in, e);
+            // a tile holds when the chain enters it at its guess, or passes over it and it made no guess (a tile that
+            // guessed and is passed over put its exit into `ex`: nothing here can be trusted then)
+            const bool over = in >= end;
+            const bool ok = !have || (over ? g == P_NONE : g == in);
+            const bool bad = have && !over && fl != 0; // a record that does not fit ends the chain: tile by tile from here
+            if (__ballot(!ok || bad) == 0) {
+                const uint32_t cc = have && !over ? c : 0;
+                const uint32_t incl = wave_inclusive_scan(cc);
+                uint32_t lp = have && !over && c > 0 ? last + 1 : 0; // (+1: P_NONE sorts lowest)
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(lp, o); if (lane >= (uint32_t)o) lp = std::max(lp, up); }
+                uint32_t lp_in = __shfl_up(lp, 1);
+                if (lane == 0) lp_in = 0;
+                my_entry = have && !over ? in : P_NONE;
+                my_rank = rank + incl - cc;
+                my_prev = lp_in ? lp_in - 1 : prev;
+                const uint32_t top = std::min(63u, tiles - t0 - 1);
+                rank += lane_u32(incl, top);
+                const uint32_t lp_top = lane_u32(lp, top);
+                if (lp_top) prev = lp_top - 1;
+                e = std::max(e, lane_u32(ex, top));
+                done = true;
+            }
+        }
+        if (!done) {
+            const uint32_t here = std::min(64u, tiles - t0);
+            for (uint32_t i = 0; i < here; i++) {
+                const uint32_t tend = std::min((t0 + i) * PTILE + PTILE, n);
+                uint32_t entry = P_NONE;
+                const uint32_t r0 = rank, p0 = prev;
+                if (status == 0 && e < tend) {
+                    entry = e;
+                    if (lane_u32(g, i) == e) {
+                        rank += lane_u32(c, i);
+                        if (lane_u32(c, i) > 0) prev = lane_u32(last, i);
+                        if (lane_u32(fl, i)) status = 1;
+                        e = lane_u32(x, i);
+                    } else {
+                        // the tile guessed another entry: its records are walked here, one by one
+                        uint32_t q = e;
+                        while (q < tend) {
+                            if (n - q < 4) { status = 1; break; }
+                            const uint32_t len = (uint32_t)src[q] | ((uint32_t)src[q + 1] << 8) | ((uint32_t)src[q + 2] << 16) | ((uint32_t)src[q + 3] << 24);
+                            if (len > n - q - 4) { status = 1; break; }
+                            prev = q;
+                            rank++;
+                            q += 4 + len;
+                        }
+                        e = q;
+                    }
+                }
+                if (lane == i) { my_entry = entry; my_rank = r0; my_prev = p0; }
+            }
+        }
+        if (have) {
+            gptr<uint32_t> w = words + (uint64_t)mine * TW_WORDS;
+            w[TW_ENTRY] = my_entry; w[TW_RANK] = my_rank; w[TW_PREV] = my_prev;
+        }
+    }
+    if (lane == 0) {
+        page[PW_STATUS] = status;
+        page[PW_COUNT] = rank;
+        page[PW_END] = e; // the page's end, or the record that does not fit
+        page[PW_DST_RANK] = P_NONE;
+    }
+}
+
+// Pass three: the tiles again from their true entries; offsets and bytes.
+__global__ __launch_bounds__(PT) void plain_bytes_copy_kernel(const DevPage* __restrict__ pages, const uint32_t* __restrict__ items) {
+    __shared__ PbShared sh;
+    const DevPage& pg = pages[items[blockIdx.x]];
+    if (pg.lengths == nullptr) return;
+    const uint64_t n = pg.src_len;
+    const uint64_t tiles = (n + PTILE - 1) / PTILE;
+    gptr<uint32_t> words = (gptr<uint32_t>)pg.lengths;
+    gptr<uint32_t> page = words + tiles * TW_WORDS;
+    gptr<uint8_t> dst = as_global(pg.dst);
+    gptr<uint32_t> offsets = as_global(pg.offsets);
+    const uint64_t dst_cap = pg.dst_cap, offsets_cap = pg.offsets_cap;
+    const uint32_t lane = threadIdx.x;
+    const uint64_t valid_end = page[PW_END];  // bytes from here on belong to no record
+    const uint32_t total = page[PW_COUNT];
+    for (uint64_t tile = blockIdx.y; tile < tiles; tile += gridDim.y) {
+        const Tile t = make_tile(pg, tile);
+        gptr<const uint32_t> w = words + tile * TW_WORDS;
+        const uint32_t entry = w[TW_ENTRY], rank0 = w[TW_RANK], prev0 = w[TW_PREV];
+        lds_sync();
+        stage_tile(sh, t);
+        lds_sync();
+        if (entry != P_NONE) resolve_tile(sh, t, entry - (uint32_t)t.base);
+        else { sh.starts[lane] = 0; sh.reach[lane] = 0; lds_sync(); }
+        // ---- records in front of every sub-chunk: a prefix sum over the lanes ----
+        unsigned long long starts = sh.starts[lane];
+        {
+            const uint32_t c = (uint32_t)__builtin_popcountll(starts);
+            const uint32_t incl = wave_inclusive_scan(c);
+            if ((lane & 63) == 63) sh.wave_sum[lane >> 6] = incl;
+            lds_sync();
+            uint32_t front = incl - c;
+            for (uint32_t wv = 0; wv < (lane >> 6); wv++) front += sh.wave_sum[wv];
+            sh.before[lane] = (uint16_t)front;
+        }
+        // ---- offsets, and the first record that does not fit the destination ----
+        {
+            uint32_t k = rank0 + sh.before[lane];  // the record's number in the page
+            unsigned long long m = starts;
+            while (m && k < total) {                // (the record that failed is not one)
+                const uint32_t bit = (uint32_t)__builtin_ctzll(m);
+                m &= m - 1;
+                const uint64_t pos = t.base + lane * PSUB + bit;
+                const uint64_t next = t.base + (m ? lane * PSUB + (uint32_t)__builtin_ctzll(m) : sh.exit_[lane]);
+                const uint64_t out = pos - 4ull * k, len = next - pos - 4;
+                if ((uint64_t)k + 2 <= offsets_cap) offsets[k] = (uint32_t)out;
+                else if ((uint64_t)k + 1 == std::max<uint64_t>(offsets_cap, 1)) { page[PW_OFF_OUT] = (uint32_t)out; page[PW_OFF_POS] = (uint32_t)pos; }
+                if (out <= dst_cap && out + len > dst_cap) {
+                    page[PW_DST_RANK] = k; page[PW_DST_OUT] = (uint32_t)out; page[PW_DST_LEN] = (uint32_t)len; page[PW_DST_POS] = (uint32_t)pos;
+                }
+                k++;
+            }
+            // records past the page's count (what follows a record that failed) are nobody's
+            if (rank0 + sh.before[lane] + (uint32_t)__builtin_popcountll(starts) > total) {
+                unsigned long long keep = starts;
+                uint32_t drop = rank0 + sh.before[lane] + (uint32_t)__builtin_popcountll(starts) - total;
+                while (drop-- && keep) keep &= ~(1ull << (63 - (uint32_t)__builtin_clzll(keep)));
+                starts = keep;
+                sh.starts[lane] = starts;
+            }
+        }
+        // ---- the bytes of length fields: four from every start, some of them in the next sub-chunk ----
+        lds_sync();
+        {
+            unsigned long long headers = starts | starts << 1 | starts << 2 | starts << 3;
+            if (lane > 0) {
+                const unsigned long long ps = sh.starts[lane - 1];
+                headers |= ps >> 61 | ps >> 62 | ps >> 63; // starts at bytes 61, 62, 63 of the sub-chunk before
+            } else if (prev0 != P_NONE && (uint64_t)prev0 + 4 > t.base) {
+                headers |= (1ull << ((uint64_t)prev0 + 4 - t.base)) - 1; // the last record of the tiles before
+            }
+            sh.headers[lane] = headers;
+        }
+        lds_sync();
+        // ---- the copy: a thread takes 16 bytes of the tile at a time, neighbours take neighbouring bytes ----
+        for (uint32_t c16 = lane; c16 * 16 < t.bytes; c16 += PT) {
+            const uint32_t at = c16 * 16, sub = at / PSUB, sh_bits = at % PSUB;
+            const unsigned long long st = sh.starts[sub], hd = sh.headers[sub];
+            const uint32_t st16 = (uint32_t)(st >> sh_bits) & 0xffffu, hd16 = (uint32_t)(hd >> sh_bits) & 0xffffu;
+            // records that start before byte `at`
+            uint64_t k = (uint64_t)rank0 + sh.before[sub] + (uint32_t)__builtin_popcountll(st & ((1ull << sh_bits) - 1));
+            const uint64_t q = t.base + at;
+            const uint32_t have = std::min<uint32_t>(16, t.bytes - at);
+            const bool whole = have == 16 && q + 16 <= valid_end;
+            if (whole && hd16 == 0) {
+                // sixteen bytes of one value
+                const uint64_t out = q - 4 * k;
+                if (k > 0 && out + 16 <= dst_cap) {
+                    *(gptr<u32x4_a1>)(dst + out) = *reinterpret_cast<const u32x4*>(&sh.stage[at / 4]);
+                    continue;
+                }
+            } else if (whole && __builtin_popcount(st16) == 1 && __builtin_popcount(hd16) == 4 && (hd16 >> __builtin_ctz(st16)) == 0xfu) {
+                // one whole length field inside: the twelve bytes around it close up, still on a 4-byte grid
+                const uint32_t h = (uint32_t)__builtin_ctz(st16);
+                const uint64_t out = q - 4 * k;
+                if ((k > 0 || h == 0) && out + 12 <= dst_cap) {
+                    const u32x4 v = *reinterpret_cast<const u32x4*>(&sh.stage[at / 4]);
+                    const unsigned __int128 x = (unsigned __int128)v.x | (unsigned __int128)v.y << 32 | (unsigned __int128)v.z << 64 |
+                                                (unsigned __int128)v.w << 96;
+                    const unsigned __int128 low = h ? x & (((unsigned __int128)1 << (8 * h)) - 1) : 0;
+                    const unsigned __int128 high = h < 12 ? (x >> (8 * h + 32)) << (8 * h) : 0;
+                    const unsigned __int128 r = low | high;
+                    u32x3_a1 o;
+                    o.x = (uint32_t)r; o.y = (uint32_t)(r >> 32); o.z = (uint32_t)(r >> 64);
+                    *(gptr<u32x3_a1>)(dst + out) = o;
+                    continue;
+                }
+            }
+            const uint8_t* bytes = reinterpret_cast<const uint8_t*>(sh.stage) + at;
+            for (uint32_t i = 0; i < have; i++) {
+                if (st16 >> i & 1) k++;
+                if ((hd16 >> i & 1) || k == 0 || q + i >= valid_end) continue;
+                const uint64_t out = q + i - 4 * k;
+                if (out < dst_cap) dst[out] = bytes[i];
+            }
+        }
+    }
+}
+
+// Pass four, one thread per page: the page's result (plain.go:76-94 walks record by record: the first
+// record that fails in any way decides).
+__global__ void plain_bytes_finish_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                          const uint32_t* __restrict__ items, uint32_t n_items) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_items) return;
+    const DevPage& pg = pages[items[i]];
+    if (pg.lengths == nullptr) return;
+    DevResult* res = &results[items[i]];
+    const uint64_t n = pg.src_len;
+    const uint64_t tiles = (n + PTILE - 1) / PTILE;
+    gptr<const uint32_t> page = (gptr<const uint32_t>)pg.lengths + tiles * TW_WORDS;
+    const uint64_t total = page[PW_COUNT], end = page[PW_END];
+    const uint64_t offsets_cap = pg.offsets_cap;
+    // candidates, by record number: the record the offsets have no room for, the record the destination has
+    // no room for, the record that does not fit the page
+    const uint64_t k_off = std::max<uint64_t>(offsets_cap, 1) - 1;
+    const uint64_t k_dst = page[PW_DST_RANK] == P_NONE ? ~0ull : page[PW_DST_RANK];
+    int32_t status = PQD_OK;
+    int64_t arg = 0;
+    uint64_t values = total, bytes = end - 4 * total, consumed = n;
+    if (k_off < total && k_off <= k_dst) {
+        status = PQD_ERR_OFFSETS_TOO_SMALL; arg = (int64_t)(k_off + 2);
+        values = k_off; bytes = page[PW_OFF_OUT]; consumed = page[PW_OFF_POS];
+    } else if (k_dst < total) {
+        status = PQD_ERR_DST_TOO_SMALL; arg = (int64_t)((uint64_t)page[PW_DST_OUT] + page[PW_DST_LEN]);
+        values = k_dst; bytes = page[PW_DST_OUT]; consumed = page[PW_DST_POS];
+    } else if (page[PW_STATUS] != 0) {
+        status = PQD_ERR_UNEXPECTED_EOF; arg = PQD_EOF_PLAIN_BYTE_ARRAY;
+        consumed = end;
+    } else if (total + 1 > offsets_cap) {
+        status = PQD_ERR_OFFSETS_TOO_SMALL; arg = (int64_t)(total + 1);
+    } else {
+        as_global(pg.offsets)[total] = (uint32_t)bytes;
+    }
+    res->status = status;
+    res->arg = arg;
+    res->out_values = values;
+    res->out_bytes = bytes;
+    res->consumed = consumed;
+    res->total = values;
+}
+
+} // namespace
+
+uint64_t plain_bytes_scratch_words(uint64_t src_len) {
+    // pages this path does not take: positions are kept in 32 bits
+    if (src_len == 0 || src_len > 0xfff00000ull) return 0;
+    return ((src_len + PTILE - 1) / PTILE) * TW_WORDS + PW_WORDS;
+}
+
+void launch_plain_byte_array(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_bytes,
+                             hipStream_t stream) {
+    if (n_items == 0) return;
+    launch_plain_byte_array_walk(pages, results, items, n_items, stream); // the pages without scratch
+    if (max_bytes == 0) return;                                           // (no page has any)
+    const uint32_t gy = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (max_bytes + PTILE - 1) / PTILE), 16384);
+    hipLaunchKernelGGL(plain_bytes_guess_kernel, dim3(n_items, gy), dim3(PT), 0, stream, pages, items);
+    hipLaunchKernelGGL(plain_bytes_chain_kernel, dim3(n_items), dim3(64), 0, stream, pages, items);
+    hipLaunchKernelGGL(plain_bytes_copy_kernel, dim3(n_items, gy), dim3(PT), 0, stream, pages, items);
+    hipLaunchKernelGGL(plain_bytes_finish_kernel, dim3((n_items + 63) / 64), dim3(64), 0, stream, pages, results, items, n_items);
+}
+
+} // namespace pqd

@@ -26,6 +26,7 @@ struct pqd_ctx {
     int32_t dict_lds;     // dictionary pages through an LDS-resident dictionary: 0 never, 1 when it pays, 2 whenever possible
     uint64_t dict_lds_max_bytes; // dictionaries above this size never take that path
     uint64_t dict_lds_cap_bytes; // at most this much of a dictionary is kept in LDS (0: all that fits)
+    int32_t plain_tiled;         // PLAIN byte arrays by many workgroups per page (0: one wavefront per page)
     std::mutex mu;                          // guards the list below
     std::vector<struct pqd::Workspace*> idle; // workspaces of the host entry points that no call is using
     void* levels_scratch; // this device's copy of the static workspace of pqd_optional_expand_noalloc (null: look-up failed)
@@ -298,8 +299,14 @@ void launch_bss(const DevPage* pages, DevResult* results, const uint32_t* items,
                 hipStream_t stream);
 void launch_plain_fixed(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_bytes,
                         hipStream_t stream);
-void launch_plain_byte_array(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
+// PLAIN byte arrays: pages that were given scratch (plain_bytes_scratch_words(src_len) 32-bit words in
+// DevPage::lengths) are decoded by many workgroups each, the others by one wavefront each; max_bytes is the
+// longest page with scratch (0: none has any)
+uint64_t plain_bytes_scratch_words(uint64_t src_len);
+void launch_plain_byte_array(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_bytes,
                              hipStream_t stream);
+void launch_plain_byte_array_walk(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
+                                  hipStream_t stream);
 void launch_dlba(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_bytes,
                  hipStream_t stream);
 void launch_dba(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_values,
