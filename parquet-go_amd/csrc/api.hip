@@ -77,6 +77,15 @@ inline bool hip_ok(hipError_t e) { return e == hipSuccess; }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// Entries of an RLE page's run table: a run takes at least a byte of the page, and the run that holds value p
+// is at most the p-th, so neither more than the page has bytes nor more than the values that can be written.
+uint64_t run_table_entries(const DevPage& d) {
+    const uint64_t stride = d.dst_stride > 0 ? (uint64_t)d.dst_stride : (uint64_t)(d.elem_width > 0 ? d.elem_width : 1);
+    uint64_t values = d.dst_cap / stride + 1;
+    if (d.num_values >= 0 && (uint64_t)d.num_values < values) values = (uint64_t)d.num_values;
+    return std::min<uint64_t>(d.src_len, values) + 1;
+}
+
 int32_t elem_width_of(int32_t kind, int32_t bit_width) {
     switch (kind) {
         case PQD_KIND_LEVELS: return 1;
@@ -330,7 +339,7 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
             if (!d.fused && dict_enc) d.elem_width = 4;
             if (d.fused && d.elem_width == 8) d.family = FAM_RLE_DICT8;
             if (d.fused && d.elem_width == 4) d.family = FAM_RLE_DICT4;
-            d.runs_cap = p.src_len + 1;
+            d.runs_cap = run_table_entries(d);
             runs_entries += d.runs_cap;
             m.primary = (int32_t)b->items.size();
             b->items.push_back(d);
@@ -353,7 +362,7 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
                 ix.dst_stride = 0;
                 ix.dst_cap = cap * 4;
                 // (dst is pointed into the arena after the carve)
-                ix.runs_cap = p.src_len + 1;
+                ix.runs_cap = run_table_entries(ix);
                 runs_entries += ix.runs_cap;
                 const int32_t ix_idx = (int32_t)b->items.size();
                 b->items.push_back(ix);

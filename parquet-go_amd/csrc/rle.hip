@@ -36,8 +36,11 @@ __device__ inline Run load_run(gptr<const Run> runs, uint64_t i) {
 }
 
 // The first entry is also kept in the page's result, where the expand kernels find it without
-// another dependent look-up.
-__device__ inline void store_run(gptr<Run> runs, uint64_t i, const Run& r, DevResult* res) {
+// another dependent look-up.  The table holds `cap` entries: as many as the page could have runs, or
+// as the values that will be written could lie in (the run of value p is at most the p-th); entries
+// past that are counted but not kept, and nobody asks for them.
+__device__ inline void store_run(gptr<Run> runs, uint64_t cap, uint64_t i, const Run& r, DevResult* res) {
+    if (i >= cap) return;
     u32x4 w;
     w.x = r.out_start; w.y = r.in_off; w.z = r.value; w.w = r.count_kind;
     *(gptr<u32x4>)(runs + i) = w;
@@ -320,7 +323,7 @@ __device__ inline void rle_index_page(uint32_t* ring, ICtl& ctl, const DevPage& 
                     r.in_off = h.in_off;
                     r.value = h.value;
                     r.count_kind = ((uint32_t)h.nvals << 1) | (h.kind == 1 ? 1u : 0u);
-                    store_run(runs, n_runs + __popcll(recm & ((1ull << tid) - 1)), r, res);
+                    store_run(runs, pg.runs_cap, n_runs + __popcll(recm & ((1ull << tid) - 1)), r, res);
                 }
                 publish_steps(tile_run, n_steps, keep && h.kind != 2, total + x - h.nvals, h.nvals,
                               (uint32_t)(n_runs + __popcll(recm & ((1ull << tid) - 1))), tid);
@@ -346,7 +349,7 @@ __device__ inline void rle_index_page(uint32_t* ring, ICtl& ctl, const DevPage& 
                             r.in_off = g.in_off;
                             r.value = g.value;
                             r.count_kind = ((uint32_t)g.nvals << 1) | (g.kind == 1 ? 1u : 0u);
-                            store_run(runs, n_runs, r, res);
+                            store_run(runs, pg.runs_cap, n_runs, r, res);
                         }
                         publish_steps(tile_run, n_steps, tid == 0, total, g.nvals, (uint32_t)n_runs, tid);
                         n_runs++;
@@ -369,7 +372,7 @@ __device__ inline void rle_index_page(uint32_t* ring, ICtl& ctl, const DevPage& 
         res->status = ctl.status;
         res->bw = (int32_t)bw;
         res->arg = ctl.arg;
-        res->n_runs = ctl.n_runs;
+        res->n_runs = ctl.n_runs < pg.runs_cap ? ctl.n_runs : pg.runs_cap;
         res->total = ctl.total;
         res->consumed = ctl.pos >= mis ? ctl.pos - mis : 0;
         if (EXPAND_FIELDS) {
@@ -716,7 +719,7 @@ __global__ __launch_bounds__(CKT) void rle_chunk_emit_kernel(const DevPage* __re
             r.in_off = h.in_off;
             r.value = h.value;
             r.count_kind = ((uint32_t)h.nvals << 1) | (h.kind == 1 ? 1u : 0u);
-            store_run(runs, r_at, r, &results[item]);
+            store_run(runs, pg.runs_cap, r_at, r, &results[item]);
         }
         publish_steps(tile_run, n_steps, rec, v_at, h.nvals, (uint32_t)r_at, lane);
     }
@@ -731,7 +734,7 @@ __global__ __launch_bounds__(CKT) void rle_chunk_emit_kernel(const DevPage* __re
             res->status = PQD_OK;
             res->bw = (int32_t)ps.bw;
             res->arg = 0;
-            res->n_runs = n_runs;
+            res->n_runs = n_runs < pg.runs_cap ? n_runs : pg.runs_cap;
             res->total = total;
             res->consumed = w.end - w.mis;
             res->out_values = 0;
