@@ -1,0 +1,116 @@
+"""Device-resident rates of the page encoders: DELTA_BINARY_PACKED int64 / int32 on the headline's
+page shape, RLE_DICTIONARY index pages, BYTE_STREAM_SPLIT, and the dictionary bounds.  Values are
+generated on the host, placed in HBM once, encoded as one batch per line; the time is the whole
+pqd_encode_batch call (descriptor upload, kernels, results back, one synchronisation), the kernels'
+own durations come from rocprofv3 --kernel-trace over this script.  Output is checked against the
+CPU checker's encoders on a sample of the pages."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+import __graft_entry__ as entry  # noqa: E402
+
+pkg = entry.load_package()
+from oracle import pqoracle as O  # noqa: E402
+from parquet_go_amd._lib import EncodePage  # noqa: E402
+
+ctx = pkg.Context(0)
+L = pkg.lib()
+DEV = "cuda:0"
+rng = np.random.default_rng(4)
+
+
+def run(name, uniq, replicate, encoding, kind, bit_width, check, steps=10):
+    """uniq: list of numpy value arrays; each is used `replicate` times (distinct copies in HBM)."""
+    n_pages = len(uniq) * replicate
+    srcs, caps, ns = [], [], []
+    for k in range(n_pages):
+        v = uniq[k % len(uniq)]
+        t = torch.from_numpy(v.view(np.uint8).copy()).to(DEV)
+        n = v.size // bit_width if kind == pkg.KIND.FIXED_LEN_BYTE_ARRAY else v.size
+        srcs.append(t)
+        ns.append(n)
+        caps.append(int(L.pqd_encode_bound(encoding, kind, bit_width, n)))
+    slot = (max(caps) + 255) // 256 * 256
+    dst = torch.empty(n_pages * slot, dtype=torch.uint8, device=DEV)
+    pages = (EncodePage * n_pages)()
+    for k in range(n_pages):
+        p = pages[k]
+        p.src, p.n_values, p.dst, p.dst_cap = srcs[k].data_ptr(), ns[k], dst.data_ptr() + k * slot, slot
+        p.encoding, p.kind, p.bit_width = encoding, kind, bit_width
+    ws = torch.empty(int(L.pqd_encode_workspace_size(pages, n_pages)) + 256, dtype=torch.uint8, device=DEV)
+    stream = torch.cuda.current_stream(0).cuda_stream
+
+    def once():
+        rc = L.pqd_encode_batch(ctx.handle, pages, n_pages, ws.data_ptr(), ws.numel(), stream)
+        assert rc == 0
+    once()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(steps):
+        t0 = time.perf_counter()
+        once()
+        best = min(best, time.perf_counter() - t0)
+    assert all(pages[k].status == 0 for k in range(n_pages))
+    out_bytes = sum(pages[k].out_bytes for k in range(n_pages))
+    in_bytes = sum(u.nbytes for u in uniq) * replicate
+    host = dst.cpu().numpy()
+    for k in list(range(min(3, n_pages))) + [n_pages - 1]:
+        assert host[k * slot: k * slot + pages[k].out_bytes].tobytes() == check(uniq[k % len(uniq)]), (name, k)
+    print(f"{name:44s} {n_pages:5d} pages  {best * 1e6:9.1f} us per call  values {in_bytes / 1e6:8.1f} MB -> pages {out_bytes / 1e6:8.1f} MB  "
+          f"{in_bytes / best / 1e9:7.1f} GB/s of values, {(in_bytes + out_bytes) / best / 1e9:7.1f} GB/s read + written", flush=True)
+
+
+E, K = pkg.ENC, pkg.KIND
+ts = [1_600_000_000_000_000_000 + np.cumsum(rng.integers(1_000_000, 1_004_096, size=131072, dtype=np.int64)) for _ in range(16)]
+run("DELTA_BINARY_PACKED int64 timestamps 128 Ki", ts, 128, E.DELTA_BINARY_PACKED, K.INT64, 0, lambda v: bytes(O.delta_encode_int64(v)))
+ids = [np.cumsum(rng.integers(0, 200, size=262144, dtype=np.int64)).astype(np.int32) for _ in range(16)]
+run("DELTA_BINARY_PACKED int32 ids 256 Ki", ids, 64, E.DELTA_BINARY_PACKED, K.INT32, 0, lambda v: bytes(O.delta_encode_int32(v)))
+wide = [rng.integers(-2**62, 2**62, size=131072, dtype=np.int64) for _ in range(8)]
+run("DELTA_BINARY_PACKED int64 random 128 Ki", wide, 64, E.DELTA_BINARY_PACKED, K.INT64, 0, lambda v: bytes(O.delta_encode_int64(v)))
+idx = [rng.integers(0, 65536, size=262144, dtype=np.int32) for _ in range(8)]
+run("RLE_DICTIONARY indexes bw16 uniform 256 Ki", idx, 32, E.RLE_DICTIONARY, K.INT32, 0, lambda v: bytes(O.rle_dict_encode_int32(v)))
+
+
+def runs_of(n, top, mean):
+    out = np.empty(n, np.int32)
+    at = 0
+    while at < n:
+        k = int(rng.geometric(1.0 / mean))
+        out[at: at + k] = rng.integers(0, top)
+        at += k
+    return out
+
+
+idx2 = [runs_of(262144, 1000, 40) for _ in range(8)]
+run("RLE_DICTIONARY indexes runs of 40, 256 Ki", idx2, 32, E.RLE_DICTIONARY, K.INT32, 0, lambda v: bytes(O.rle_dict_encode_int32(v)))
+dbl = [rng.standard_normal(262144) for _ in range(8)]
+run("BYTE_STREAM_SPLIT double 256 Ki", dbl, 32, E.BYTE_STREAM_SPLIT, K.DOUBLE, 0, lambda v: bytes(O.bss_encode(v.tobytes(), 8)))
+flt = [rng.standard_normal(524288).astype(np.float32) for _ in range(8)]
+run("BYTE_STREAM_SPLIT float 512 Ki", flt, 32, E.BYTE_STREAM_SPLIT, K.FLOAT, 0, lambda v: bytes(O.bss_encode(v.tobytes(), 4)))
+
+# dictionary bounds: 16 Mi indexes into a 64 Ki-entry int64 dictionary
+d = torch.from_numpy(rng.integers(-2**62, 2**62, size=65536, dtype=np.int64)).to(DEV)
+ix = torch.from_numpy(rng.integers(0, 65536, size=1 << 24, dtype=np.int32)).to(DEV)
+out = torch.empty(2, dtype=torch.int64, device=DEV)
+st = torch.empty(2, dtype=torch.int64, device=DEV)
+bws = torch.empty(64 << 10, dtype=torch.uint8, device=DEV)
+stream = torch.cuda.current_stream(0).cuda_stream
+ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+for _ in range(3):
+    assert L.pqd_dict_bounds_device(ctx.handle, K.INT64, 0, d.data_ptr(), d.numel(), ix.data_ptr(), ix.numel(), out.data_ptr(), bws.data_ptr(),
+                                    bws.numel(), st.data_ptr(), stream) == 0
+ev[0].record()
+for _ in range(10):
+    L.pqd_dict_bounds_device(ctx.handle, K.INT64, 0, d.data_ptr(), d.numel(), ix.data_ptr(), ix.numel(), out.data_ptr(), bws.data_ptr(), bws.numel(),
+                             st.data_ptr(), stream)
+ev[1].record()
+torch.cuda.synchronize()
+us = ev[0].elapsed_time(ev[1]) * 100
+g = d[ix.long()]
+assert out.tolist() == [int(g.min()), int(g.max())] and st.tolist() == [0, 0]
+print(f"{'dictionaryBounds int64, 16 Mi indexes, 64 Ki entries':44s}        {us:9.1f} us per call  {ix.numel() * 4 / us / 1e3:7.1f} GB/s of indexes", flush=True)
