@@ -408,6 +408,85 @@ int pqd_chunk_plan_pages(const pqd_page_header* headers, uint64_t n_headers, con
                          const void* chunk_dev, const pqd_column_info* column, pqd_page* items, pqd_page_part* parts,
                          uint64_t cap, uint64_t* n_items, int64_t* status_arg);
 
+/* ---- file footer: schema, row groups and chunk ranges (host) -------------- */
+
+/* format.CompressionCodec (format/parquet.go) */
+enum { PQD_CODEC_UNCOMPRESSED = 0, PQD_CODEC_SNAPPY = 1, PQD_CODEC_GZIP = 2, PQD_CODEC_LZO = 3, PQD_CODEC_BROTLI = 4,
+       PQD_CODEC_LZ4 = 5, PQD_CODEC_ZSTD = 6, PQD_CODEC_LZ4_RAW = 7 };
+
+typedef struct pqd_file_info {
+    int32_t  version;            /* FileMetaData.version */
+    int32_t  is_encrypted;       /* an encryption_algorithm is present (plaintext footer of an encrypted file) */
+    int64_t  num_rows;
+    uint64_t n_schema;           /* schema elements, the root included */
+    uint64_t n_columns;          /* leaves of the schema */
+    uint64_t n_row_groups;
+    uint64_t n_chunks;           /* n_row_groups * n_columns */
+    uint64_t names_bytes;        /* what the column paths take in `names` */
+    uint64_t footer_bytes_read;  /* the thrift structure ends here; more bytes are a signature (file.go:177-197) */
+} pqd_file_info;
+
+/* A leaf of the schema, depth first: what Column holds (column.go:26-57) and what
+ * pqd_column_info needs. */
+typedef struct pqd_file_column {
+    int32_t  kind;               /* PQD_KIND_* (= format.Type + 1), as pqd_column_info takes it */
+    int32_t  type_length;        /* FIXED_LEN_BYTE_ARRAY */
+    int32_t  repetition;         /* format.FieldRepetitionType of the leaf: 0 required, 1 optional, 2 repeated */
+    int32_t  converted_type;     /* deprecated.ConvertedType, -1 when absent */
+    uint8_t  max_definition_level; /* Column.setLevels (column.go:234-280) */
+    uint8_t  max_repetition_level;
+    uint8_t  depth;
+    uint8_t  reserved0;
+    uint32_t schema_index;       /* of the leaf in FileMetaData.schema */
+    uint32_t name_offset;        /* Column.Path joined with '.', names[name_offset .. + name_len) */
+    uint32_t name_len;
+} pqd_file_column;
+
+typedef struct pqd_file_row_group {
+    int64_t num_rows;
+    int64_t total_byte_size;
+    int64_t file_offset;           /* 0 when absent */
+    int64_t total_compressed_size; /* 0 when absent */
+} pqd_file_row_group;
+
+/* ColumnChunk.meta_data (format/parquet.go:987-1050).  The pages of the chunk are
+ * file[offset .. offset + total_compressed_size) (file.go:1119-1128): that range, read or
+ * decompressed page by page, is what pqd_chunk_scan_pages takes. */
+typedef struct pqd_file_chunk {
+    int64_t  num_values;
+    int64_t  offset;             /* dictionary_page_offset when there is one, else data_page_offset */
+    int64_t  total_compressed_size;
+    int64_t  total_uncompressed_size;
+    int64_t  data_page_offset;
+    int64_t  dictionary_page_offset; /* 0 when absent */
+    int32_t  kind;               /* PQD_KIND_* of ColumnMetaData.type */
+    int32_t  codec;              /* PQD_CODEC_* */
+    uint32_t encodings;          /* bit e set: format.Encoding e is listed */
+    int32_t  has_metadata;       /* 0: the chunk carries no meta_data */
+    int32_t  is_encrypted;       /* encrypted_column_metadata is present */
+    int32_t  reserved;
+} pqd_file_chunk;
+
+/* The tail of OpenFile (file.go:108-131): `tail` = the last `tail_len` >= 8 bytes of a file
+ * of `file_size` bytes; gives where the footer (the thrift FileMetaData) lies.
+ * PQD_ERR_INVALID_ARGUMENT when the magic is not "PAR1", PQD_ERR_NOT_SUPPORTED for "PARE"
+ * (encrypted footer), PQD_ERR_UNEXPECTED_EOF when the length does not fit the file. */
+int pqd_file_footer_range(const uint8_t* tail, uint64_t tail_len, uint64_t file_size, uint64_t* footer_offset,
+                          uint64_t* footer_len);
+
+/* format.FileMetaData (format/parquet.go:1386-1436) into flat tables: the leaf columns as
+ * columnLoader.open walks the schema (column.go:369-521), the row groups, and one chunk per
+ * row group and column, chunks[row_group * n_columns + column].  `info` is always filled;
+ * PQD_ERR_DST_TOO_SMALL when a table does not hold its rows (call with capacities 0 to size
+ * them), PQD_ERR_UNEXPECTED_EOF for malformed thrift (*status_arg = offset),
+ * PQD_ERR_INVALID_ARGUMENT for a schema whose groups claim more children than there are
+ * elements or that nests or repeats beyond 255 (*status_arg = schema index), or a row group
+ * whose chunks are not one per leaf (*status_arg = row group; column.go:223-228). */
+int pqd_file_parse_footer(const uint8_t* footer, uint64_t footer_len, pqd_file_info* info, pqd_file_column* columns,
+                          uint64_t column_cap, pqd_file_row_group* row_groups, uint64_t row_group_cap,
+                          pqd_file_chunk* chunks, uint64_t chunk_cap, char* names, uint64_t names_cap,
+                          int64_t* status_arg);
+
 #ifdef __cplusplus
 }
 #endif

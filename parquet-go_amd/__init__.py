@@ -9,4 +9,4 @@ parquet-go's own.  The directory name carries a hyphen, so import it through
 from . import _lib  # noqa: F401
 from ._lib import (Context, Page, PqdError, STATUS, KIND, ENC, lib, library_path)  # noqa: F401
 from .runtime import Batch, DeviceBuffer, decode_pages, to_device  # noqa: F401
-from . import chunk, encoding, levels, sharding  # noqa: F401
+from . import chunk, encoding, file, levels, sharding  # noqa: F401

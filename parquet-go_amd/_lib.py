@@ -108,6 +108,34 @@ class PagePart(C.Structure):
     _fields_ = [("page", C.c_uint64), ("role", C.c_int32), ("reserved", C.c_int32), ("src_offset", C.c_uint64)]
 
 
+class FileInfo(C.Structure):
+    """struct pqd_file_info"""
+    _fields_ = [("version", C.c_int32), ("is_encrypted", C.c_int32), ("num_rows", C.c_int64), ("n_schema", C.c_uint64),
+                ("n_columns", C.c_uint64), ("n_row_groups", C.c_uint64), ("n_chunks", C.c_uint64), ("names_bytes", C.c_uint64),
+                ("footer_bytes_read", C.c_uint64)]
+
+
+class FileColumn(C.Structure):
+    """struct pqd_file_column"""
+    _fields_ = [("kind", C.c_int32), ("type_length", C.c_int32), ("repetition", C.c_int32), ("converted_type", C.c_int32),
+                ("max_definition_level", C.c_uint8), ("max_repetition_level", C.c_uint8), ("depth", C.c_uint8),
+                ("reserved0", C.c_uint8), ("schema_index", C.c_uint32), ("name_offset", C.c_uint32), ("name_len", C.c_uint32)]
+
+
+class FileRowGroup(C.Structure):
+    """struct pqd_file_row_group"""
+    _fields_ = [("num_rows", C.c_int64), ("total_byte_size", C.c_int64), ("file_offset", C.c_int64),
+                ("total_compressed_size", C.c_int64)]
+
+
+class FileChunk(C.Structure):
+    """struct pqd_file_chunk"""
+    _fields_ = [("num_values", C.c_int64), ("offset", C.c_int64), ("total_compressed_size", C.c_int64),
+                ("total_uncompressed_size", C.c_int64), ("data_page_offset", C.c_int64), ("dictionary_page_offset", C.c_int64),
+                ("kind", C.c_int32), ("codec", C.c_int32), ("encodings", C.c_uint32), ("has_metadata", C.c_int32),
+                ("is_encrypted", C.c_int32), ("reserved", C.c_int32)]
+
+
 # every symbol include/pqd.h declares: name -> (restype, argtypes)
 _vp, _u64, _i64, _int = C.c_void_p, C.c_uint64, C.c_int64, C.c_int
 _pu64, _pi64 = C.POINTER(C.c_uint64), C.POINTER(C.c_int64)
@@ -150,6 +178,9 @@ SYMBOLS = {
     "pqd_chunk_scan_pages": (_int, [_vp, _u64, _i64, C.POINTER(PageHeader), _u64, _pu64, _pi64]),
     "pqd_chunk_plan_pages": (_int, [C.POINTER(PageHeader), _u64, _vp, _u64, _vp, C.POINTER(ColumnInfo), C.POINTER(Page),
                                     C.POINTER(PagePart), _u64, _pu64, _pi64]),
+    "pqd_file_footer_range": (_int, [_vp, _u64, _u64, _pu64, _pu64]),
+    "pqd_file_parse_footer": (_int, [_vp, _u64, C.POINTER(FileInfo), C.POINTER(FileColumn), _u64, C.POINTER(FileRowGroup), _u64,
+                                     C.POINTER(FileChunk), _u64, _vp, _u64, _pi64]),
 }
 
 _lib = None

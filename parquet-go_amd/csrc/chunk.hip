@@ -15,98 +15,11 @@
 #include <string.h>
 
 #include "pqd_internal.h"
+#include "thrift_compact.h"
 
 namespace {
 
-// Thrift compact protocol reader over a byte range; `ok` drops to false at the first
-// read past the end or malformed element and stays there.
-struct Compact {
-    const uint8_t* p;
-    const uint8_t* end;
-    bool ok = true;
-    int depth = 0;
-    static constexpr int MAX_DEPTH = 32; // nested structs, lists, sets and maps
-
-    uint8_t byte() {
-        if (p >= end) { ok = false; return 0; }
-        return *p++;
-    }
-    uint64_t uvarint() {
-        uint64_t x = 0;
-        for (int s = 0; s < 70; s += 7) {
-            const uint8_t c = byte();
-            if (!ok) return 0;
-            x |= (uint64_t)(c & 0x7f) << s;
-            if (c < 0x80) return x;
-        }
-        ok = false;
-        return 0;
-    }
-    int64_t zigzag() {
-        const uint64_t u = uvarint();
-        return (int64_t)(u >> 1) ^ -(int64_t)(u & 1);
-    }
-    void advance(uint64_t n) {
-        if ((uint64_t)(end - p) < n) { ok = false; p = end; return; }
-        p += n;
-    }
-    // compact.go type codes: 1 TRUE, 2 FALSE, 3 I8, 4 I16, 5 I32, 6 I64, 7 DOUBLE, 8 BINARY,
-    // 9 LIST, 10 SET, 11 MAP, 12 STRUCT
-    void skip(int t, bool in_collection) {
-        if (!ok) return;
-        switch (t) {
-        case 1: case 2: if (in_collection) advance(1); break; // booleans of a collection take a byte
-        case 3: advance(1); break;
-        case 4: case 5: case 6: (void)uvarint(); break;
-        case 7: advance(8); break;
-        case 8: advance(uvarint()); break;
-        // collections nest like structs do: the same depth limit, or a run of list headers
-        // (0x19 0x19 ...) would recurse once per byte
-        case 9: case 10: {
-            if (++depth > MAX_DEPTH) { ok = false; return; }
-            const uint8_t h = byte();
-            uint64_t n = h >> 4;
-            if (n == 15) n = uvarint();
-            for (uint64_t i = 0; i < n && ok; i++) skip(h & 0xf, true);
-            depth--;
-            break;
-        }
-        case 11: {
-            if (++depth > MAX_DEPTH) { ok = false; return; }
-            const uint64_t n = uvarint();
-            if (n > 0) {
-                const uint8_t kv = byte();
-                for (uint64_t i = 0; i < n && ok; i++) { skip(kv >> 4, true); skip(kv & 0xf, true); }
-            }
-            depth--;
-            break;
-        }
-        case 12: skip_struct(); break;
-        default: ok = false;
-        }
-    }
-    // One field header: false at STOP.  Booleans carry their value in the type.
-    bool field(int* id, int* type, int* last) {
-        const uint8_t h = byte();
-        if (!ok || h == 0) return false;
-        *type = h & 0xf;
-        const int delta = h >> 4;
-        *id = delta ? *last + delta : (int)zigzag();
-        *last = *id;
-        return ok;
-    }
-    void skip_struct() {
-        if (++depth > MAX_DEPTH) { ok = false; return; }
-        int id, type, last = 0;
-        while (field(&id, &type, &last)) skip(type, false);
-        depth--;
-    }
-    int32_t i32(int type) {
-        if (type != 4 && type != 5 && type != 6 && type != 3) { ok = false; return 0; }
-        if (type == 3) return (int8_t)byte();
-        return (int32_t)zigzag();
-    }
-};
+using pqd::Compact;
 
 // crc32.ChecksumIEEE (polynomial 0xEDB88320, reflected), eight bytes per step.
 struct Crc32 {
