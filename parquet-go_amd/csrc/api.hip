@@ -48,6 +48,8 @@ struct pqd_batch {
     uint32_t* d_rle_tile_item[6] = {}; // grid tile -> position in the family list (null: the kernel searches the prefix)
     uint64_t rle_tiles[6] = {};
     uint64_t lds_dict_bytes[6] = {}; // LDS families: the largest dictionary of the family, in bytes
+    uint64_t lds_sliced_bytes[6] = {}; // ... the largest one that is to be sliced over a group of workgroups
+    bool lds_unsliced[6] = {};       // ... some dictionary of the family is not to be sliced
     uint32_t launches = 0;           // times the batch has been launched
     LdsPlan lds_plan[6];             // ... their launch shape
     uint32_t* d_lds_wg_item[6] = {}; // ... the item each workgroup starts in
@@ -269,6 +271,12 @@ int pqd_ctx_create(int device, pqd_ctx** out) {
     ctx->dict_lds_max_bytes = lds_max != nullptr ? strtoull(lds_max, nullptr, 10) : LDS_DICT_DEFAULT_MAX_BYTES;
     const char* lds_cap = getenv("PQD_DICT_LDS_CAP_BYTES");
     ctx->dict_lds_cap_bytes = lds_cap != nullptr ? strtoull(lds_cap, nullptr, 10) : 0;
+    // PQD_DICT_SLICES: over how many workgroups a dictionary larger than LDS may be sliced (0 or 1: never);
+    // PQD_DICT_SLICE_BYTES: bytes per slice (tests slice small dictionaries)
+    const char* sl = getenv("PQD_DICT_SLICES");
+    ctx->dict_slices = sl != nullptr ? (uint32_t)strtoul(sl, nullptr, 10) : 2;
+    const char* slb = getenv("PQD_DICT_SLICE_BYTES");
+    ctx->dict_slice_bytes = slb != nullptr ? strtoull(slb, nullptr, 10) : 0;
     // PLAIN byte-array pages: one wavefront per page, or many workgroups per page when the batch has too few
     // pages to fill the chip with wavefronts (PQD_PLAIN_TILED=0 / 1: never / always, for comparisons and tests)
     const char* tiled = getenv("PQD_PLAIN_TILED");
@@ -493,10 +501,17 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
                 }
                 if (copied > tiles * RLE_TILE * (uint64_t)(from == FAM_RLE_DICT8 ? 8 : 4)) continue;
             }
+            uint64_t slice_above = 0, slice_upto = 0;
+            rle_dict_slice_range(ctx->dict_lds_cap_bytes, ctx->n_cus, ctx->dict_slices, ctx->dict_slice_bytes, &slice_above, &slice_upto);
             for (DevPage& d : b->items)
                 if (candidate(d)) {
                     d.family = to;
-                    b->lds_dict_bytes[rle_grid(to)] = std::max<uint64_t>(b->lds_dict_bytes[rle_grid(to)], d.dict_len * (uint64_t)d.elem_width);
+                    const uint64_t bytes = d.dict_len * (uint64_t)d.elem_width;
+                    b->lds_dict_bytes[rle_grid(to)] = std::max<uint64_t>(b->lds_dict_bytes[rle_grid(to)], bytes);
+                    if (bytes > slice_above && bytes <= slice_upto)
+                        b->lds_sliced_bytes[rle_grid(to)] = std::max<uint64_t>(b->lds_sliced_bytes[rle_grid(to)], bytes);
+                    else
+                        b->lds_unsliced[rle_grid(to)] = true;
                 }
         }
     }
@@ -606,11 +621,12 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
     for (int g = 0; g < RLE_GRIDS; g++) {
         if (!is_lds_family(RLE_FAMILY[g]) || b->rle_tiles[g] == 0) continue;
         const std::vector<uint32_t>& list = b->fam[RLE_FAMILY[g]].items;
-        const LdsPlan plan = rle_dict_lds_plan(b->rle_tiles[g], b->lds_dict_bytes[g], ctx->dict_lds_cap_bytes, ctx->n_cus);
+        const LdsPlan plan = rle_dict_lds_plan(b->rle_tiles[g], b->lds_dict_bytes[g], b->lds_sliced_bytes[g], !b->lds_unsliced[g], ctx->dict_lds_cap_bytes, ctx->n_cus,
+                                               ctx->dict_slice_bytes);
         b->lds_plan[g] = plan;
-        lds_wg[g].resize(2 * (size_t)plan.grid);
-        for (uint32_t w = 0, k = 0; w < plan.grid; w++) {
-            const uint64_t t0 = b->rle_tiles[g] * w / plan.grid, t1 = b->rle_tiles[g] * (w + 1) / plan.grid;
+        lds_wg[g].resize(2 * (size_t)plan.groups);
+        for (uint32_t w = 0, k = 0; w < plan.groups; w++) {
+            const uint64_t t0 = b->rle_tiles[g] * w / plan.groups, t1 = b->rle_tiles[g] * (w + 1) / plan.groups;
             while (k + 1 < list.size() && rle_prefix[g][k + 1] <= t0) k++;
             lds_wg[g][2 * w] = k;
             uint32_t k1 = k;

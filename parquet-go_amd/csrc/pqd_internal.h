@@ -26,6 +26,8 @@ struct pqd_ctx {
     int32_t dict_lds;     // dictionary pages through an LDS-resident dictionary: 0 never, 1 when it pays, 2 whenever possible
     uint64_t dict_lds_max_bytes; // dictionaries above this size never take that path
     uint64_t dict_lds_cap_bytes; // at most this much of a dictionary is kept in LDS (0: all that fits)
+    uint32_t dict_slices;        // most workgroups one dictionary is sliced over (below 2: never)
+    uint64_t dict_slice_bytes;   // bytes of a slice (0: the default)
     int32_t plain_tiled;         // PLAIN byte arrays by many workgroups per page (0: one wavefront per page)
     std::mutex mu;                          // guards the list below
     std::vector<struct pqd::Workspace*> idle; // workspaces of the host entry points that no call is using
@@ -283,10 +285,19 @@ struct LdsPlan {                     // launch shape of a family, fixed when the
     uint32_t grid = 0;               // persistent workgroups
     uint32_t lds_bytes = 0, dict_bytes = 0, tab_cap = 0;
     bool part = false;               // some dictionary of the family is larger than what LDS holds of it
+    // slices > 1: the workgroups stand in `groups` groups of `slices` (grid = groups * slices), every workgroup of a
+    // group holds slice_bytes of the dictionary and all of them walk the group's tiles; otherwise groups == grid
+    uint32_t slices = 1, groups = 0, slice_bytes = 0;
 };
-LdsPlan rle_dict_lds_plan(uint64_t n_tiles, uint64_t max_dict_bytes, uint64_t cap_bytes, uint32_t n_cus);
-// wg_item[2b], wg_item[2b + 1]: positions in the family list of the items that hold workgroup b's first and last
-// tile (tiles n_tiles * b / grid and n_tiles * (b + 1) / grid - 1); seg_last[i]: the last position from i on whose
+// Dictionaries of more than *above and at most *upto bytes are sliced over a group of workgroups (*upto 0: none
+// is); max_slices: most workgroups in a group (below 2: no slicing); slice_bytes_opt: bytes per slice (0: the default)
+void rle_dict_slice_range(uint64_t cap_bytes, uint32_t n_cus, uint32_t max_slices, uint64_t slice_bytes_opt, uint64_t* above, uint64_t* upto);
+// max_dict_bytes: the family's largest dictionary; sliced_dict_bytes: its largest inside the sliced range (0: none);
+// all_sliced: every dictionary of the family lies in that range (only then is the family sliced)
+LdsPlan rle_dict_lds_plan(uint64_t n_tiles, uint64_t max_dict_bytes, uint64_t sliced_dict_bytes, bool all_sliced, uint64_t cap_bytes,
+                          uint32_t n_cus, uint64_t slice_bytes_opt);
+// wg_item[2b], wg_item[2b + 1]: positions in the family list of the items that hold group b's first and last
+// tile (tiles n_tiles * b / groups and n_tiles * (b + 1) / groups - 1); seg_last[i]: the last position from i on whose
 // item shares item i's dictionary; pk_flag: the chunked index's per-page flags; launch: how many times the batch
 // has been launched, this launch included
 void launch_rle_dict_lds(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,

@@ -1310,9 +1310,9 @@ struct LdItem {
 
 template <int ELEM>
 struct LdDict {
-    const typename LdElem<ELEM>::T* lds;  // the first lds_n entries
+    const typename LdElem<ELEM>::T* lds;  // entries [lo, lo + lds_n)
     gptr<const typename LdElem<ELEM>::T> mem;
-    uint32_t lds_n;
+    uint32_t lds_n, lo;
     uint32_t launch;               // number of this launch of the batch (tags the out-of-range positions)
     uint64_t len;
 };
@@ -1330,8 +1330,8 @@ __device__ inline void ld_lookup(const LdDict<ELEM>& d, DevResult* res, uint64_t
                                  typename LdElem<ELEM>::T (&x)[G]) {
 #pragma unroll
     for (int g = 0; g < G; g++) {
-        const uint32_t idx = v[g];
-        if (idx < d.lds_n) x[g] = d.lds[idx];
+        const uint32_t idx = v[g], rel = idx - d.lo;
+        if (rel < d.lds_n) x[g] = d.lds[rel];
         else if ((uint64_t)idx < d.len) x[g] = d.mem[idx];
         else {
             x[g] = 0;
@@ -1751,6 +1751,7 @@ __global__ __launch_bounds__(LDT) void rle_dict_lds_kernel(const DevPage* __rest
         dict.mem = (gptr<const T>)as_global(p0.dict);
         dict.len = p0.dict_len;
         dict.lds_n = dict.len < dict_cap_bytes / ELEM ? (uint32_t)dict.len : dict_cap_bytes / ELEM;
+        dict.lo = 0;
         dict.launch = launch;
         // the fast form reads entry 0 for lanes whose index lies elsewhere: there has to be one, and all of
         // the dictionary has to be in LDS unless this is the kernel that also looks in memory
@@ -1849,19 +1850,283 @@ __global__ __launch_bounds__(LDT) void rle_dict_lds_kernel(const DevPage* __rest
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// A dictionary of a few LDS sizes, sliced over neighbouring CUs.  Random 8-byte gathers from a
+// dictionary that LDS cannot hold each pull a whole cache line into the CU; the sliced form
+// never gathers from memory: the persistent workgroups stand in groups of S, the s-th of a
+// group keeps entries [s * E, (s + 1) * E) in LDS, ALL of a group walk the same tiles, and each
+// writes just the values whose index falls into its slice (an index outside the dictionary is
+// the first slice's).  The values of a tile therefore leave as S sets of masked stores from S
+// CUs; the group's workgroups are b, b + 8, b + 16 ... (blocks eight apart have been observed to
+// share an L2), so the partial lines meet there -- placement is a matter of speed only, every
+// value is written exactly once wherever the workgroups run.  Lanes hold every 64th value of a
+// tile, so one store instruction covers 64 neighbouring values.  The launch is only made for
+// families all of whose dictionaries are larger than LDS and need at most S slices.  What it
+// costs: every 64 bytes of output are written by S requests instead of one, and the write path
+// of a CU takes a request per four or five cycles however few of its bytes are enabled: at two
+// slices that is cheaper than the gathers it replaces, from four on it is not (measured).
+
+typedef uint32_t u32_a1 __attribute__((aligned(1)));
+constexpr uint32_t LD_SLICE_STEPS = RLE_TILE / 64 / 2; // values per lane and HALF tile
+constexpr uint32_t LD_SLICE_MAX_BW = 25;               // a field and up to seven bits of shift fit one 4-byte load
+constexpr uint32_t LD_MAX_SLICES = 8;
+
+enum { LD_WHOLE = 0, LD_PART = 1, LD_SLICED = 2 };
+template <int MODE> struct LdWords { uint64_t w[LD_PAIRS]; };
+template <> struct LdWords<LD_SLICED> { uint32_t w[LD_SLICE_STEPS]; };
+
+template <int ELEM, int MODE>
+__device__ inline void ld_fetch(const LdTile& tl, uint32_t half, LdWords<MODE>& W) {
+    if constexpr (MODE == LD_SLICED) {
+        // a lane's fields lie 64 fields = 8 * bw bytes apart: one address per lane, a uniform step (all below 2^24)
+        const uint32_t lane = threadIdx.x & 63;
+        const uint32_t bit = tl.s0 + __umul24(half * LD_SLICE_STEPS * 64 + lane, tl.bw); // < 8 + 2048 * 25
+        gptr<const uint8_t> p = tl.packed + (bit >> 3);
+        const uint32_t step = 8 * tl.bw;
+#pragma unroll
+        for (uint32_t q = 0; q < LD_SLICE_STEPS; q++) W.w[q] = *(gptr<const u32_a1>)(p + q * step);
+    } else {
+        ld_prefetch<ELEM>(tl, half, W.w);
+    }
+}
+
+// Half of a fast tile for the workgroup that holds dictionary entries [dict.lo, dict.lo + dict.lds_n):
+// the values whose index lies there, and for the first slice (`owner`) zero for an index outside
+// the dictionary, whose first position is reported as everywhere else.
+template <int ELEM>
+__device__ inline void ld_slice_half(const LdDict<ELEM>& dict, bool owner, const LdTile& tl, uint32_t half,
+                                     const uint32_t (&w)[LD_SLICE_STEPS]) {
+    typedef typename LdElem<ELEM>::T T;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t bw = tl.bw;
+    const uint32_t mask = (1u << bw) - 1; // bw <= 25 here
+    const uint32_t len = dict.len > 0xffffffffull ? 0xffffffffu : (uint32_t)dict.len;
+    uint32_t bad = 0xffffffffu;
+    const uint32_t j0 = half * LD_SLICE_STEPS * 64 + lane;
+    const uint32_t s = (tl.s0 + __umul24(j0, bw)) & 7; // the same in every step: 64 fields are whole bytes
+    // The tile's destination as a buffer: a lane that has nothing to write stores at an offset outside it, which
+    // the hardware drops.  Every step is then one store instruction without a branch around it, so the waits
+    // for the packed words fetched ahead count the memory operations in flight exactly and never wait for stores.
+    const uint64_t dst_u = ld_uniform((uint64_t)(uintptr_t)(uint8_t*)tl.dst);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(uintptr_t)dst_u, 0, (int)(RLE_TILE * ELEM), 0x00020000);
+    constexpr uint32_t B = 8; // look-ups in flight together
+#pragma unroll
+    for (uint32_t q0 = 0; q0 < LD_SLICE_STEPS; q0 += B) {
+        T x[B];
+#pragma unroll
+        for (uint32_t k = 0; k < B; k++) {
+            const uint32_t rel = ((w[q0 + k] >> s) & mask) - dict.lo;
+            x[k] = dict.lds[rel < dict.lds_n ? rel : 0];
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < B; k++) asm volatile("" : "+v"(x[k])); // all of them asked for before the first is stored
+#pragma unroll
+        for (uint32_t k = 0; k < B; k++) {
+            const uint32_t q = q0 + k;
+            const uint32_t idx = (w[q] >> s) & mask;
+            const bool hit = idx - dict.lo < dict.lds_n;
+            const bool out = owner && idx >= len;
+            const uint32_t j = j0 + q * 64;
+            bad = !out || bad < j ? bad : j;
+            const uint32_t off = hit || out ? j * ELEM : 0xffffffffu;
+            if (ELEM == 8) {
+                u32x2 o;
+                o.x = hit ? (uint32_t)x[k] : 0u; o.y = hit ? (uint32_t)((uint64_t)x[k] >> 32) : 0u;
+                __builtin_amdgcn_raw_buffer_store_b64(o, rsrc, (int)off, 0, 0);
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b32(hit ? (uint32_t)x[k] : 0u, rsrc, (int)off, 0, 0);
+            }
+        }
+    }
+    if (bad != 0xffffffffu) ld_record_bad(tl.res, dict.launch, tl.t0 + bad);
+}
+
+template <int ELEM, int MODE>
+__device__ inline void ld_half(const LdDict<ELEM>& dict, bool owner, const LdTile& tl, uint32_t half, const LdWords<MODE>& W) {
+    if constexpr (MODE == LD_SLICED) ld_slice_half<ELEM>(dict, owner, tl, half, W.w);
+    else ld_fast_half<ELEM, MODE == LD_PART>(dict, tl, half, W.w);
+}
+
+// One segment (the tiles [.., seg_end) of consecutive items that share a dictionary) by one
+// workgroup: entries [dict.lo, dict.lo + dict.lds_n) of the dictionary into LDS, then the tiles
+// first, first + stride, ... by the wavefront.  In sliced mode those are every workgroup's of the
+// group: `owner` (the first slice) writes the zeros of indexes outside the dictionary, and the
+// tiles the fast form leaves are decoded whole by one workgroup each, the k-th such tile of the
+// wavefront by workgroup k mod share_n (this one is share_k), which reads memory for the
+// indexes outside its slice.
+template <int ELEM, int MODE>
+__device__ inline void ld_segment(uint8_t* ld_shared, const LdDict<ELEM>& dict, bool owner, uint32_t share_n, uint32_t share_k,
+                                  const DevPage* __restrict__ pages,
+                                  DevResult* __restrict__ results, const uint32_t* __restrict__ items,
+                                  const uint64_t* __restrict__ tile_prefix, const uint32_t* __restrict__ pk_flag, uint32_t li,
+                                  uint64_t first, uint64_t stride, uint64_t seg_end, u32x4* tab, uint32_t tab_cap) {
+    const uint32_t tid = threadIdx.x;
+    const bool allow_fast = dict.len > 0 && (MODE != LD_WHOLE || dict.lds_n == dict.len);
+    const uint32_t max_bw = MODE == LD_SLICED ? LD_SLICE_MAX_BW : LD_FAST_MAX_BW;
+    LdItem it;
+    it.pg = nullptr; it.res = nullptr; it.total = it.n_runs = it.n_out = 0; it.tile_lo = it.tile_hi = 0; it.bw = 0;
+    it.only.out_start = it.only.in_off = it.only.value = it.only.count_kind = 0;
+    uint32_t wi = li;
+    uint64_t u = first;
+    const bool have = u < seg_end;
+    LdTile cur;
+    LdWords<MODE> Wa, Wb;
+    for (auto& x : Wa.w) x = 0;
+    for (auto& x : Wb.w) x = 0;
+    cur.fast = false; cur.n = 0; cur.u = 0; cur.wi = 0;
+    if (have) {
+        ld_setup<ELEM>(pages, results, items, tile_prefix, pk_flag, u, it, wi, allow_fast, cur);
+        if (cur.fast && cur.bw > max_bw) cur.fast = false;
+        if (cur.fast) ld_fetch<ELEM, MODE>(cur, 0, Wa);
+    }
+    {
+        // the slice's bytes, as rle_dict_lds_kernel copies a dictionary
+        const uint32_t bytes = dict.lds_n * ELEM, body = bytes & ~15u;
+        gptr<const uint8_t> g = (gptr<const uint8_t>)dict.mem + (uint64_t)dict.lo * ELEM;
+        constexpr uint32_t U = 4, PASS = U * LDT * 16;
+        const uint32_t last = body >= 16 ? body - 16 : 0;
+        u32x4_a1 wd[U];
+        uint32_t at[U];
+        if (body >= 16) {
+#pragma unroll
+            for (uint32_t k = 0; k < U; k++) {
+                const uint32_t c = tid * 16 + k * LDT * 16;
+                at[k] = c < last ? c : last;
+                wd[k] = *(gptr<const u32x4_a1>)(g + at[k]);
+            }
+        }
+        __syncthreads(); // nobody still reads what LDS held for the segment before
+        if (body >= 16) {
+#pragma unroll
+            for (uint32_t k = 0; k < U; k++) *reinterpret_cast<u32x4*>(ld_shared + at[k]) = wd[k];
+            for (uint32_t base = PASS; base < body; base += PASS) {
+#pragma unroll
+                for (uint32_t k = 0; k < U; k++) {
+                    const uint32_t c = base + tid * 16 + k * LDT * 16;
+                    at[k] = c < last ? c : last;
+                    wd[k] = *(gptr<const u32x4_a1>)(g + at[k]);
+                }
+#pragma unroll
+                for (uint32_t k = 0; k < U; k++) *reinterpret_cast<u32x4*>(ld_shared + at[k]) = wd[k];
+            }
+        }
+        for (uint32_t b = body + tid; b < bytes; b += LDT) ld_shared[b] = g[b];
+    }
+    __syncthreads();
+    bool any_slow = false;
+    if (have) {
+        for (;;) {
+            const uint64_t un = u + stride;
+            const bool more = un < seg_end;
+            LdTile nxt;
+            nxt.fast = false; nxt.n = 0; nxt.u = 0; nxt.wi = 0;
+            if (more) {
+                ld_setup<ELEM>(pages, results, items, tile_prefix, pk_flag, un, it, wi, allow_fast, nxt);
+                if (nxt.fast && nxt.bw > max_bw) nxt.fast = false;
+            }
+            if (cur.fast) {
+                ld_fetch<ELEM, MODE>(cur, 1, Wb);
+                ld_half<ELEM, MODE>(dict, owner, cur, 0, Wa);
+                if (nxt.fast) ld_fetch<ELEM, MODE>(nxt, 0, Wa);
+                ld_half<ELEM, MODE>(dict, owner, cur, 1, Wb);
+            } else {
+                any_slow = any_slow || cur.n > 0;
+                if (nxt.fast) ld_fetch<ELEM, MODE>(nxt, 0, Wa);
+            }
+            if (!more) break;
+            cur = nxt;
+            u = un;
+        }
+    }
+    if (any_slow) {
+        uint32_t wj = li, k = 0;
+        for (uint64_t v = first; v < seg_end; v += stride, k++) {
+            if (MODE == LD_SLICED && k % share_n != share_k) continue;
+            LdTile tl;
+            LdItem it2;
+            it2.pg = nullptr; it2.res = nullptr; it2.total = it2.n_runs = it2.n_out = 0; it2.tile_lo = it2.tile_hi = 0; it2.bw = 0;
+            it2.only.out_start = it2.only.in_off = it2.only.value = it2.only.count_kind = 0;
+            ld_setup<ELEM>(pages, results, items, tile_prefix, pk_flag, v, it2, wj, allow_fast, tl);
+            if (tl.fast && tl.bw > max_bw) tl.fast = false;
+            if (!tl.fast && tl.n > 0) ld_wave_tile<ELEM>(dict, it2, (v - it2.tile_lo) * RLE_TILE, tl.n, tab, tab_cap);
+        }
+    }
+}
+
+template <int ELEM>
+__global__ __launch_bounds__(LDT) void rle_dict_slice_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                             const uint32_t* __restrict__ items, uint32_t n_items,
+                                                             const uint64_t* __restrict__ tile_prefix, uint64_t n_tiles,
+                                                             const uint32_t* __restrict__ wg_item, const uint32_t* __restrict__ seg_last,
+                                                             const uint32_t* __restrict__ pk_flag, uint32_t launch,
+                                                             uint32_t dict_cap_bytes, uint32_t tab_cap, uint32_t slice_bytes,
+                                                             uint32_t n_slices, uint32_t groups_per_xcd) {
+    typedef typename LdElem<ELEM>::T T;
+    extern __shared__ __attribute__((aligned(16))) uint8_t ld_shared[];
+    const uint32_t tid = threadIdx.x, wave = ld_uniform(tid >> 6);
+    u32x4* tab = reinterpret_cast<u32x4*>(ld_shared + dict_cap_bytes) + (size_t)wave * tab_cap;
+    // workgroups b, b + 8, ... , b + 8 (S - 1) form a group; the groups share out the family's tiles
+    const uint32_t xcd = blockIdx.x & 7, in_xcd = blockIdx.x >> 3;
+    const uint32_t slice = in_xcd % n_slices, group = xcd * groups_per_xcd + in_xcd / n_slices, n_groups = 8 * groups_per_xcd;
+    const uint64_t T0 = n_tiles * group / n_groups, T1 = n_tiles * (group + 1) / n_groups;
+    uint32_t li = wg_item[2 * group];
+    // ---- run tables of the group's pages, by every workgroup of the group (same tables, same values; nobody waits) ----
+    if (T0 < T1) {
+        const uint32_t li_last = wg_item[2 * group + 1];
+        uint32_t* ring = reinterpret_cast<uint32_t*>(ld_shared + (size_t)wave * LD_INDEX_BYTES);
+        ICtl& ctl = *reinterpret_cast<ICtl*>(ld_shared + (size_t)wave * LD_INDEX_BYTES + IRING_BYTES);
+        for (uint32_t k = li + wave; k <= li_last; k += LD_WAVES) {
+            const uint32_t item = items[k];
+            const DevPage& pg = pages[item];
+            uint32_t bw0, off0;
+            uint64_t total0;
+            if (ld_chunk_indexed(pg, pk_flag) || ld_simple_page(pg, bw0, total0, off0)) continue;
+            rle_index_page<false>(ring, ctl, pg, &results[item], tid & 63);
+        }
+    }
+    __syncthreads();
+    const uint32_t slice_entries = slice_bytes / ELEM;
+    uint64_t t = T0;
+    while (t < T1) {
+        while (tile_prefix[li + 1] <= t) li++;
+        const uint64_t seg_hi = tile_prefix[seg_last[li] + 1];
+        const uint64_t seg_end = seg_hi < T1 ? seg_hi : T1;
+        const DevPage& p0 = pages[items[li]];
+        LdDict<ELEM> dict;
+        dict.lds = reinterpret_cast<const T*>(ld_shared);
+        dict.mem = (gptr<const T>)as_global(p0.dict);
+        dict.len = p0.dict_len;
+        dict.launch = launch;
+        const uint64_t cap_entries = dict_cap_bytes / ELEM;
+        if (dict.len > cap_entries && dict.len <= (uint64_t)slice_entries * n_slices) {
+            const uint64_t lo = (uint64_t)slice * slice_entries;
+            if (lo < dict.len) { // (a slice past the dictionary's end has nothing to write)
+                dict.lo = (uint32_t)lo;
+                dict.lds_n = dict.len - lo < slice_entries ? (uint32_t)(dict.len - lo) : slice_entries;
+                const uint32_t n_active = (uint32_t)((dict.len + slice_entries - 1) / slice_entries);
+                ld_segment<ELEM, LD_SLICED>(ld_shared, dict, slice == 0, n_active, slice, pages, results, items, tile_prefix, pk_flag, li,
+                                            t + wave, LD_WAVES, seg_end, tab, tab_cap);
+            }
+        }
+        t = seg_end;
+    }
+}
+
 } // namespace
 
 // Largest dynamic LDS allocation a workgroup of rle_dict_lds_kernel may ask for.
 constexpr uint32_t LD_MAX_LDS = 160 * 1024 - 1024;
 constexpr uint32_t LD_MIN_TAB = 32;    // run-table entries per wavefront, at least / at most
 constexpr uint32_t LD_MAX_TAB = 512;
+constexpr uint32_t LD_SLICE_BYTES = 128 * 1024; // of a dictionary per workgroup when it is sliced over a group of them
 
 bool rle_dict_lds_init() {
     // dynamic LDS above the default limit has to be asked for once per kernel
     static const bool ok = [] {
         bool r = true;
         for (const void* fn : {reinterpret_cast<const void*>(&rle_dict_lds_kernel<8, false>), reinterpret_cast<const void*>(&rle_dict_lds_kernel<8, true>),
-                               reinterpret_cast<const void*>(&rle_dict_lds_kernel<4, false>), reinterpret_cast<const void*>(&rle_dict_lds_kernel<4, true>)})
+                               reinterpret_cast<const void*>(&rle_dict_lds_kernel<4, false>), reinterpret_cast<const void*>(&rle_dict_lds_kernel<4, true>),
+                               reinterpret_cast<const void*>(&rle_dict_slice_kernel<8>), reinterpret_cast<const void*>(&rle_dict_slice_kernel<4>)})
             r = r && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LD_MAX_LDS) == hipSuccess;
         (void)hipGetLastError();
         return r;
@@ -1871,12 +2136,29 @@ bool rle_dict_lds_init() {
 
 uint32_t rle_dict_lds_capacity() { return LD_MAX_LDS - LD_WAVES * LD_MIN_TAB * (uint32_t)sizeof(Run); }
 
-LdsPlan rle_dict_lds_plan(uint64_t n_tiles, uint64_t max_dict_bytes, uint64_t cap_bytes, uint32_t n_cus) {
+// What LDS holds of a dictionary at most, and the size of a slice, under the experiment knobs.
+static uint32_t ld_dict_cap(uint64_t cap_bytes) {
+    uint32_t c = rle_dict_lds_capacity();
+    if (cap_bytes > 0 && c > cap_bytes) c = (uint32_t)cap_bytes;
+    c &= ~15u;
+    return c < 16 ? 16 : c;
+}
+static uint32_t ld_slice_bytes(uint64_t cap_bytes, uint64_t slice_bytes_opt) {
+    return (uint32_t)std::min<uint64_t>(slice_bytes_opt > 0 ? (slice_bytes_opt & ~15ull) : LD_SLICE_BYTES, ld_dict_cap(cap_bytes));
+}
+
+void rle_dict_slice_range(uint64_t cap_bytes, uint32_t n_cus, uint32_t max_slices, uint64_t slice_bytes_opt, uint64_t* above, uint64_t* upto) {
+    const uint64_t sb = ld_slice_bytes(cap_bytes, slice_bytes_opt);
+    const uint64_t most = std::min<uint64_t>(std::min<uint32_t>(max_slices, LD_MAX_SLICES), n_cus / 8);
+    *above = ld_dict_cap(cap_bytes);
+    *upto = most >= 2 && sb >= 16 ? most * sb : 0;
+}
+
+LdsPlan rle_dict_lds_plan(uint64_t n_tiles, uint64_t max_dict_bytes, uint64_t sliced_dict_bytes, bool all_sliced, uint64_t cap_bytes,
+                          uint32_t n_cus, uint64_t slice_bytes_opt) {
     LdsPlan p;
     // LDS: the dictionary (or the part of it that fits), then a run table per wavefront from what is left
-    p.dict_bytes = (uint32_t)std::min<uint64_t>((max_dict_bytes + 15) & ~15ull, rle_dict_lds_capacity());
-    if (cap_bytes > 0 && p.dict_bytes > cap_bytes) p.dict_bytes = (uint32_t)cap_bytes;
-    p.dict_bytes &= ~15u;
+    p.dict_bytes = (uint32_t)std::min<uint64_t>((max_dict_bytes + 15) & ~15ull, ld_dict_cap(cap_bytes));
     if (p.dict_bytes < 16) p.dict_bytes = 16;
     p.part = max_dict_bytes > p.dict_bytes;
     p.tab_cap = std::min((LD_MAX_LDS - p.dict_bytes) / (LD_WAVES * (uint32_t)sizeof(Run)), LD_MAX_TAB);
@@ -1887,6 +2169,21 @@ LdsPlan rle_dict_lds_plan(uint64_t n_tiles, uint64_t max_dict_bytes, uint64_t ca
     const uint64_t by_work = (n_tiles + 7) / 8;
     if (grid > by_work) grid = by_work;
     p.grid = (uint32_t)std::max<uint64_t>(grid, 1);
+    p.groups = p.grid;
+    p.slices = 1;
+    // the largest dictionary of the family that is to be sliced says over how many workgroups
+    if (all_sliced && sliced_dict_bytes > p.dict_bytes) {
+        const uint32_t sb = ld_slice_bytes(cap_bytes, slice_bytes_opt);
+        const uint64_t n_sl = (sliced_dict_bytes + sb - 1) / sb, per_xcd = n_cus / 8;
+        if (n_sl >= 2 && n_sl <= LD_MAX_SLICES && n_sl <= per_xcd) {
+            const uint64_t by_work_xcd = (by_work + 7) / 8;
+            const uint32_t gpx = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(per_xcd / n_sl, by_work_xcd));
+            p.slices = (uint32_t)n_sl;
+            p.slice_bytes = sb;
+            p.groups = 8 * gpx;
+            p.grid = p.groups * p.slices;
+        }
+    }
     return p;
 }
 
@@ -1894,6 +2191,15 @@ void launch_rle_dict_lds(const DevPage* pages, DevResult* results, const uint32_
                          const uint64_t* tile_prefix, uint64_t n_tiles, int32_t elem, const LdsPlan& plan, const uint32_t* wg_item,
                          const uint32_t* seg_last, const uint32_t* pk_flag, uint32_t launch, hipStream_t stream) {
     if (n_items == 0 || n_tiles == 0) return;
+if (plan.slices > 1) {
+#define PQD_SLICE_LAUNCH(E)                                                                                                     \
+    hipLaunchKernelGGL((rle_dict_slice_kernel<E>), dim3(plan.grid), dim3(LDT), plan.lds_bytes, stream, pages, results, items,   \
+                       n_items, tile_prefix, n_tiles, wg_item, seg_last, pk_flag, launch, plan.dict_bytes, plan.tab_cap,        \
+                       plan.slice_bytes, plan.slices, plan.groups / 8)
+        if (elem == 8) PQD_SLICE_LAUNCH(8); else PQD_SLICE_LAUNCH(4);
+#undef PQD_SLICE_LAUNCH
+        return;
+    }
 #define PQD_LDS_LAUNCH(E, P)                                                                                                   \
     hipLaunchKernelGGL((rle_dict_lds_kernel<E, P>), dim3(plan.grid), dim3(LDT), plan.lds_bytes, stream, pages, results, items, \
                        n_items, tile_prefix, n_tiles, wg_item, seg_last, pk_flag, launch, plan.dict_bytes, plan.tab_cap)

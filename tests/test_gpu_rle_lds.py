@@ -1,7 +1,10 @@
-"""GPU: RLE_DICTIONARY pages decoded straight to values, with each of the three gather paths
+"""GPU: RLE_DICTIONARY pages decoded straight to values, with each of the gather paths
 forced in turn -- dictionary through the caches (PQD_DICT_LDS=0), dictionary resident in LDS
-(PQD_DICT_LDS=2), and only the first part of the dictionary in LDS with the rest read from
-memory (PQD_DICT_LDS_CAP_BYTES) -- against the CPU checker's decode + newIndexedPage fix-up +
+(PQD_DICT_LDS=2), only the first part of the dictionary in LDS with the rest read from
+memory (PQD_DICT_LDS_CAP_BYTES, PQD_DICT_SLICES=0), and the dictionary sliced over groups of
+workgroups (a family is sliced when all its dictionaries are larger than LDS and need no more
+slices than allowed; PQD_DICT_SLICE_BYTES and PQD_DICT_LDS_CAP_BYTES bring that down to the
+sizes of test_sliced_families) -- against the CPU checker's decode + newIndexedPage fix-up +
 dictionary lookup (encoding/rle/dictionary.go:30-37, dictionary.go:136-162,
 dictionary_purego.go:12-38).  Bit exact; same statuses and positions for indexes outside
 the dictionary."""
@@ -23,8 +26,13 @@ def _ctx(mode):
     if mode not in _ctxs:
         env = {"cache": {"PQD_DICT_LDS": "0"},
                "lds": {"PQD_DICT_LDS": "2", "PQD_DICT_LDS_MAX_BYTES": str(1 << 30)},
-               "part": {"PQD_DICT_LDS": "2", "PQD_DICT_LDS_MAX_BYTES": str(1 << 30), "PQD_DICT_LDS_CAP_BYTES": "4096"}}[mode]
-        keys = ("PQD_DICT_LDS", "PQD_DICT_LDS_MAX_BYTES", "PQD_DICT_LDS_CAP_BYTES")
+               "part": {"PQD_DICT_LDS": "2", "PQD_DICT_LDS_MAX_BYTES": str(1 << 30), "PQD_DICT_LDS_CAP_BYTES": "4096",
+                        "PQD_DICT_SLICES": "0"},
+               "sliced": {"PQD_DICT_LDS": "2", "PQD_DICT_LDS_MAX_BYTES": str(1 << 30), "PQD_DICT_LDS_CAP_BYTES": "4096",
+                          "PQD_DICT_SLICES": "8", "PQD_DICT_SLICE_BYTES": "2048"},
+               "sliced3": {"PQD_DICT_LDS": "2", "PQD_DICT_LDS_MAX_BYTES": str(1 << 30), "PQD_DICT_LDS_CAP_BYTES": "65536",
+                           "PQD_DICT_SLICES": "3", "PQD_DICT_SLICE_BYTES": "48000"}}[mode]
+        keys = ("PQD_DICT_LDS", "PQD_DICT_LDS_MAX_BYTES", "PQD_DICT_LDS_CAP_BYTES", "PQD_DICT_SLICES", "PQD_DICT_SLICE_BYTES")
         old = {k: os.environ.get(k) for k in keys}
         for k in keys:
             os.environ.pop(k, None)
@@ -39,7 +47,7 @@ def _ctx(mode):
     return _ctxs[mode]
 
 
-MODES = ("cache", "lds", "part")
+MODES = ("cache", "lds", "part", "sliced", "sliced3")
 
 
 def _decode(mode, specs):
@@ -71,7 +79,7 @@ def test_paths_agree_with_the_checker(mode, np_dtype, kind_name):
     kind = getattr(P.KIND, kind_name)
     rng = np.random.default_rng(hash((mode, kind_name)) % 2**32)
     cases = []
-    for dn in (1, 3, 17, 100, 513, 10000, 16384, 70000):
+    for dn in (1, 3, 17, 100, 513, 1500, 10000, 16384, 70000):
         d = rng.integers(-2**31, 2**31 - 1, size=dn).astype(np_dtype)
         for n in (1, 9, 100, 2048, 2049, 5000, 40000):
             idx = rng.integers(0, dn, size=n, dtype=np.int32)
@@ -107,7 +115,7 @@ def test_many_pages_share_and_change_dictionaries(mode):
     rng = np.random.default_rng(5)
     from parquet_go_amd.runtime import Batch, to_device, DeviceBuffer
     import torch
-    dicts = [rng.integers(-2**62, 2**62, size=dn, dtype=np.int64) for dn in (700, 16384, 5, 3000, 40000)]
+    dicts = [rng.integers(-2**62, 2**62, size=dn, dtype=np.int64) for dn in (700, 16384, 5, 1800, 3000, 40000)]
     d_dev = [to_device(d) for d in dicts]
     pages, keep, want = [], [], []
     for k in range(60):
@@ -184,6 +192,59 @@ def test_width_byte_beyond_the_dictionary(monkeypatch):
             for kind, dd in ((P.KIND.INT64, d), (P.KIND.INT32, d.astype(np.int32))):
                 out = _decode(mode, [spec(P.ENC.RLE_DICTIONARY, kind, enc, num_values=n, dictionary=dd, dst_cap=n * dd.dtype.itemsize, misalign=3)])[0]
                 assert out.status == 0 and np.array_equal(out.data.view(dd.dtype), dd[idx]), (mode, bw)
+
+
+@pytest.mark.parametrize("mode,lo_bytes,hi_bytes", [("sliced", 4096, 8 * 2048), ("sliced3", 65536, 3 * 48000)])
+@pytest.mark.parametrize("np_dtype,kind_name", [(np.int64, "INT64"), (np.int32, "INT32")])
+def test_sliced_families(mode, lo_bytes, hi_bytes, np_dtype, kind_name):
+    # every dictionary of the batch lies in the sliced range, so the launch is the sliced kernel's:
+    # one to all slices in use, fast tiles, tiles of runs, cut and zero-extended pages, indexes
+    # outside the dictionary in every kind of tile, a destination that is too small
+    P = pkg()
+    kind = getattr(P.KIND, kind_name)
+    w = np.dtype(np_dtype).itemsize
+    rng = np.random.default_rng(hash((mode, kind_name)) % 2**32)
+    lo, hi = lo_bytes // w + 1, hi_bytes // w
+    sizes = sorted({lo, lo + 1, (lo + hi) // 2, hi - 3, hi})
+    cases = []
+    for dn in sizes:
+        d = rng.integers(-2**31, 2**31 - 1, size=dn).astype(np_dtype)
+        for n in (1, 9, 100, 2048, 2049, 5000, 40000):
+            idx = rng.integers(0, dn, size=n, dtype=np.int32)
+            if n >= 100:
+                idx[20:70] = idx[20]
+            cases.append((f"d{dn}-n{n}", d, idx, n, None))
+        cases.append((f"d{dn}-runs40", d, _writer_runs(rng, 30000, dn, 40), 30000, None))
+        cases.append((f"d{dn}-runs9", d, _writer_runs(rng, 30000, dn, 9), 30000, None))
+        cases.append((f"d{dn}-runs3000", d, _writer_runs(rng, 50000, dn, 3000), 50000, None))
+        cases.append((f"d{dn}-zero-extend", d, rng.integers(0, dn, size=3000, dtype=np.int32), 9000, None))
+        cases.append((f"d{dn}-cut", d, rng.integers(0, dn, size=9000, dtype=np.int32), 2047, None))
+        cases.append((f"d{dn}-first-entries", d, rng.integers(0, 7, size=20000, dtype=np.int32), 20000, None))
+        cases.append((f"d{dn}-last-entries", d, rng.integers(dn - 7, dn, size=20000, dtype=np.int32), 20000, None))
+        for bad_at, n in ((3, 6), (2047, 5000), (2048, 5000), (4999, 5000), (12345, 40000)):
+            idx = rng.integers(0, dn, size=n, dtype=np.int32)
+            idx[bad_at] = dn + int(rng.integers(0, 5))
+            if n > bad_at + 50:
+                idx[bad_at + 40] = dn + 1000
+            cases.append((f"d{dn}-bad{bad_at}", d, idx, n, bad_at))
+    specs = []
+    for k, (label, d, idx, nv, bad) in enumerate(cases):
+        specs.append(spec(P.ENC.RLE_DICTIONARY, kind, O.rle_dict_encode_int32(idx), num_values=nv, dictionary=d,
+                          dst_cap=nv * w, misalign=k % 16))
+    d = rng.integers(-2**31, 2**31 - 1, size=hi).astype(np_dtype)
+    idx_small = rng.integers(0, hi, size=7000, dtype=np.int32)
+    specs.append(spec(P.ENC.RLE_DICTIONARY, kind, O.rle_dict_encode_int32(idx_small), num_values=7000, dictionary=d, dst_cap=7000 * w - w))
+    outs = _decode(mode, specs)
+    for (label, d_, idx, nv, bad), out in zip(cases, outs):
+        if bad is not None:
+            assert (out.status, out.arg) == (P.STATUS.INDEX_OUT_OF_BOUNDS, bad), (mode, label, out.status, out.arg)
+            continue
+        want = _want(d_, O.rle_dict_encode_int32(idx), nv)
+        assert out.status == 0 and out.out_values == nv, (mode, label, out.status, out.arg)
+        assert out.data.tobytes() == want.values.tobytes(), (mode, label)
+    got = outs[-1]
+    assert (got.status, got.arg) == (P.STATUS.DST_TOO_SMALL, 7000 * w)
+    assert got.out_values == 6999 and np.array_equal(got.data.view(np_dtype), d[idx_small[:6999]])
 
 
 def _uvarint(v):
