@@ -44,16 +44,16 @@ struct pqd_batch {
     DevResult* d_results = nullptr;
     FamilyList fam[N_FAMILIES];
     // RLE expand grids, one per RLE hybrid family
-    uint64_t* d_rle_tile_prefix[6] = {};
-    uint32_t* d_rle_tile_item[6] = {}; // grid tile -> position in the family list (null: the kernel searches the prefix)
-    uint64_t rle_tiles[6] = {};
-    uint64_t lds_dict_bytes[6] = {}; // LDS families: the largest dictionary of the family, in bytes
-    uint64_t lds_sliced_bytes[6] = {}; // ... the largest one that is to be sliced over a group of workgroups
-    bool lds_unsliced[6] = {};       // ... some dictionary of the family is not to be sliced
+    uint64_t* d_rle_tile_prefix[7] = {};
+    uint32_t* d_rle_tile_item[7] = {}; // grid tile -> position in the family list (null: the kernel searches the prefix)
+    uint64_t rle_tiles[7] = {};
+    uint64_t lds_dict_bytes[7] = {}; // LDS families: the largest dictionary of the family, in bytes
+    uint64_t lds_sliced_bytes[7] = {}; // ... the largest one that is to be sliced over a group of workgroups
+    bool lds_unsliced[7] = {};       // ... some dictionary of the family is not to be sliced
     uint32_t launches = 0;           // times the batch has been launched
-    LdsPlan lds_plan[6];             // ... their launch shape
-    uint32_t* d_lds_wg_item[6] = {}; // ... the item each workgroup starts in
-    uint32_t* d_lds_seg_last[6] = {}; // ... per item, the last one from there on with the same dictionary
+    LdsPlan lds_plan[7];             // ... their launch shape
+    uint32_t* d_lds_wg_item[7] = {}; // ... the item each workgroup starts in
+    uint32_t* d_lds_seg_last[7] = {}; // ... per item, the last one from there on with the same dictionary
     uint64_t rle_steps = 0;
     RleChunks ck; // long RLE pages indexed chunk by chunk
     // a small batch forks its independent kernel families onto the context's side streams
@@ -107,13 +107,16 @@ int32_t elem_width_of(int32_t kind, int32_t bit_width) {
 // encoding.NotSupported would answer (encoding/notsupported.go:163-197).
 // The RLE hybrid families share the index kernel; each has an expand kernel and a tile grid of its own.
 constexpr size_t SIDE_BY_SIDE_MAX_ITEMS = 1024;     // batches up to this size fork their families onto side streams
-constexpr int RLE_GRIDS = 6;
+// Level pages of at most this many steps of RLE_TILE values are decoded by a workgroup each (one workgroup writes
+// about a kilobyte per 0.2 us: beyond, the tiles of the index + expand pair, spread over the chip, are quicker)
+constexpr uint64_t RLE_PAGE_MAX_STEPS = 128;
+constexpr int RLE_GRIDS = 7;
 static_assert(RLE_GRIDS == sizeof(pqd_batch::rle_tiles) / sizeof(uint64_t), "one tile grid per RLE hybrid family");
 constexpr size_t RLE_CHUNKED_MAX_PAGES = 512;      // batches with more RLE pages than this index them one wavefront each
 constexpr uint64_t RLE_CHUNKED_MIN_BYTES = 16384;   // shorter pages are not worth cutting up ...
 constexpr uint64_t RLE_CHUNKED_MIN_BYTES_FEW = 4096; // ... unless the batch holds so few that wavefronts would idle
 constexpr size_t RLE_CHUNKED_FEW_PAGES = 128;
-constexpr int32_t RLE_FAMILY[RLE_GRIDS] = {FAM_RLE, FAM_RLE_BYTES, FAM_RLE_DICT8, FAM_RLE_DICT4, FAM_RLE_LDS8, FAM_RLE_LDS4};
+constexpr int32_t RLE_FAMILY[RLE_GRIDS] = {FAM_RLE, FAM_RLE_BYTES, FAM_RLE_DICT8, FAM_RLE_DICT4, FAM_RLE_LDS8, FAM_RLE_LDS4, FAM_RLE_PAGE};
 inline bool is_lds_family(int32_t family) { return family == FAM_RLE_LDS8 || family == FAM_RLE_LDS4; }
 // Largest dictionary that goes through the persistent kernels by default (beyond what LDS holds, the first
 // part of a dictionary is kept there and the rest read from memory: measured faster than the tile-per-workgroup
@@ -280,6 +283,10 @@ int pqd_ctx_create(int device, pqd_ctx** out) {
     // PLAIN byte-array pages: one wavefront per page, or many workgroups per page when the batch has too few
     // pages to fill the chip with wavefronts (PQD_PLAIN_TILED=0 / 1: never / always, for comparisons and tests)
     const char* tiled = getenv("PQD_PLAIN_TILED");
+    // PQD_RLE_PAGE: 0 = level pages go through the index + expand kernels like every other RLE page, 2 = all of
+    // them take the page-per-workgroup kernel, otherwise those of up to RLE_PAGE_MAX_STEPS steps do
+    const char* rp = getenv("PQD_RLE_PAGE");
+    ctx->rle_page = rp != nullptr && (rp[0] == '0' || rp[0] == '2') ? rp[0] - '0' : 1;
     ctx->plain_tiled = tiled != nullptr && (tiled[0] == '0' || tiled[0] == '1') ? tiled[0] - '0' : 2;
     // with this context's device current: where this GPU keeps the static workspace
     ctx->levels_scratch = nullptr;
@@ -516,6 +523,14 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
         }
     }
 
+    // ---- level pages: a workgroup per page, index and expansion in one launch ----
+    if (ctx->rle_page != 0) {
+        for (DevPage& d : b->items)
+            if (d.family == FAM_RLE_BYTES && d.kind == PQD_KIND_LEVELS && d.encoding == PQD_ENC_RLE && d.dst_stride <= 1 && !d.fused &&
+                (ctx->rle_page == 2 || rle_steps_of(d) <= RLE_PAGE_MAX_STEPS))
+                d.family = FAM_RLE_PAGE;
+    }
+
     // ---- family lists and the RLE tile grids ----
     std::vector<uint64_t> rle_prefix[RLE_GRIDS];
     for (uint32_t k = 0; k < b->items.size(); k++) {
@@ -526,7 +541,7 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
             const int g = rle_grid(d.family);
             const uint64_t steps = rle_steps_of(d);
             if (steps > 0x7fffffffull) { delete b; return PQD_ERR_INVALID_ARGUMENT; }
-            d.group = d.family == FAM_RLE_BYTES ? 8 : 1; // 1-byte elements: 2 KB per step is too little work for a workgroup
+            d.group = d.family == FAM_RLE_BYTES || d.family == FAM_RLE_PAGE ? 8 : 1; // 1-byte elements: 2 KB per step is too little work for a workgroup
             d.n_steps = (uint32_t)steps;
             const uint64_t tiles = (steps + d.group - 1) / d.group;
             rle_prefix[g].push_back(b->rle_tiles[g]);
@@ -555,7 +570,7 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
             const uint64_t min_bytes = n_rle <= RLE_CHUNKED_FEW_PAGES ? RLE_CHUNKED_MIN_BYTES_FEW : RLE_CHUNKED_MIN_BYTES;
             for (uint32_t k = 0; k < b->items.size(); k++) {
                 DevPage& d = b->items[k];
-                if (!is_rle(d.family) || d.src_len < min_bytes || d.src_len > 0xfff00000ull) continue;
+                if (!is_rle(d.family) || d.family == FAM_RLE_PAGE || d.src_len < min_bytes || d.src_len > 0xfff00000ull) continue;
                 if (d.num_values >= 0) {
                     // widest the values can be: the declared width, or what the dictionary's size allows
                     uint64_t width = d.bit_width > 0 ? (uint64_t)d.bit_width : 32;
@@ -613,7 +628,7 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
     bool with_tile_item[RLE_GRIDS];
     for (int g = 0; g < RLE_GRIDS; g++) {
         o_rle_prefix[g] = carve(rle_prefix[g].size() * sizeof(uint64_t));
-        with_tile_item[g] = b->rle_tiles[g] <= (1ull << 24) && !is_lds_family(RLE_FAMILY[g]); // the persistent kernel walks the prefix
+        with_tile_item[g] = b->rle_tiles[g] <= (1ull << 24) && !is_lds_family(RLE_FAMILY[g]) && RLE_FAMILY[g] != FAM_RLE_PAGE; // the persistent kernel walks the prefix
         o_rle_tile_item[g] = carve(with_tile_item[g] ? b->rle_tiles[g] * sizeof(uint32_t) : 0);
     }
     size_t o_lds_wg[RLE_GRIDS] = {}, o_lds_seg[RLE_GRIDS] = {};
@@ -809,7 +824,7 @@ int pqd_batch_launch(pqd_batch* b, void* hip_stream) {
     launch_rle_chunked(b->d_items, b->d_results, b->ck, s_rle);
     b->launches++;
     for (int g = 0; g < RLE_GRIDS; g++) {
-        if (is_lds_family(RLE_FAMILY[g])) continue; // these index their pages in the launch that decodes them
+        if (is_lds_family(RLE_FAMILY[g]) || RLE_FAMILY[g] == FAM_RLE_PAGE) continue; // these index their pages in the launch that decodes them
         const FamilyList& f = b->fam[RLE_FAMILY[g]];
         launch_rle_index(b->d_items, b->d_results, f.dev, (uint32_t)f.items.size(), b->ck.pk_flag, s_rle);
     }
@@ -819,6 +834,8 @@ int pqd_batch_launch(pqd_batch* b, void* hip_stream) {
             launch_rle_dict_lds(b->d_items, b->d_results, f.dev, (uint32_t)f.items.size(), b->d_rle_tile_prefix[g], b->rle_tiles[g],
                                 RLE_FAMILY[g] == FAM_RLE_LDS8 ? 8 : 4, b->lds_plan[g], b->d_lds_wg_item[g], b->d_lds_seg_last[g], b->ck.pk_flag,
                                 b->launches, s_rle);
+        else if (RLE_FAMILY[g] == FAM_RLE_PAGE)
+            launch_rle_pages(b->d_items, b->d_results, f.dev, (uint32_t)f.items.size(), s_rle);
         else
             launch_rle_expand(b->d_items, b->d_results, f.dev, (uint32_t)f.items.size(), b->d_rle_tile_prefix[g], b->d_rle_tile_item[g],
                               b->rle_tiles[g], RLE_FAMILY[g], s_rle);

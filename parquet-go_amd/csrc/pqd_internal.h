@@ -29,6 +29,7 @@ struct pqd_ctx {
     uint32_t dict_slices;        // most workgroups one dictionary is sliced over (below 2: never)
     uint64_t dict_slice_bytes;   // bytes of a slice (0: the default)
     int32_t plain_tiled;         // PLAIN byte arrays by many workgroups per page (0: one wavefront per page)
+    int32_t rle_page;            // level pages by a workgroup each, index and expansion in one launch (0: never)
     std::mutex mu;                          // guards the list below
     std::vector<struct pqd::Workspace*> idle; // workspaces of the host entry points that no call is using
     void* levels_scratch; // this device's copy of the static workspace of pqd_optional_expand_noalloc (null: look-up failed)
@@ -147,6 +148,7 @@ enum Family : int32_t {
     FAM_RLE_LDS8 = 15,  // RLE hybrid through a dictionary of 8-byte values held in LDS, dense destination
     FAM_RLE_LDS4 = 16,  // ... of 4-byte values
     FAM_DICT_BYTES = 17, // look-up in a BYTE_ARRAY / FIXED_LEN_BYTE_ARRAY / BOOLEAN dictionary of indexes an RLE item decoded
+    FAM_RLE_PAGE = 18,  // RLE hybrid levels, a workgroup per page: run headers followed and runs expanded in one launch
     N_FAMILIES = 20
 };
 
@@ -277,6 +279,7 @@ uint32_t rle_chunk_bytes();
 void launch_rle_chunked(const DevPage* pages, DevResult* results, const RleChunks& c, hipStream_t stream);
 void launch_rle_expand(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
                        const uint64_t* tile_prefix, const uint32_t* tile_item, uint64_t n_tiles, int32_t family, hipStream_t stream);
+void launch_rle_pages(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, hipStream_t stream);
 
 // Dictionary pages through an LDS-resident dictionary (persistent workgroups).
 bool rle_dict_lds_init();            // false: the kernels cannot get their LDS; the path is not used

@@ -1041,19 +1041,73 @@ __device__ inline void expand_tile(EShared& sh, const DevPage& pg, DevResult* re
     }
 }
 
+constexpr uint32_t GROUP_SHORT_RUN = 1024;          // runs of at most this many values are expanded by one wavefront
+constexpr uint32_t GROUP_STAGE_PAD = 16;           // bytes left free before the staged packed data
+
+// Expands the staged runs tab[0 .. nr) over the values [G0, G0 + GS) of a dense one-byte destination.
+// `stage` holds the packed bytes of the bit-packed runs: stage byte GROUP_STAGE_PAD is byte `base` of
+// the page.  Long runs are shared by the whole workgroup, short ones are dealt out to the
+// wavefronts: no run waits for another, they write disjoint parts of the destination.
+__device__ __forceinline__ void expand_runs_bytes(const u32x4* tab, uint32_t nr, const uint32_t* stage, int64_t base, const DevPage& pg,
+                                         uint64_t G0, uint32_t GS, uint32_t bw) {
+    const uint32_t tid = threadIdx.x;
+    gptr<uint8_t> dst = as_global(pg.dst);
+    const uint32_t mask = (1u << bw) - 1;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (uint32_t k = 0; k < nr; k++) {
+        const u32x4 r = tab[k];
+        const uint64_t rb = r.x, re = rb + (r.w >> 1);
+        const uint64_t s0 = rb > G0 ? rb : G0, s1 = re < G0 + GS ? re : G0 + GS;
+        if (s1 <= s0) continue;
+        const uint32_t sn = (uint32_t)(s1 - s0);
+        const bool shared = sn > GROUP_SHORT_RUN;
+        if (!shared && (k & 3) != wave) continue;
+        const uint32_t lid = shared ? tid : (tid & 63), team = shared ? ET : 64;
+        if (!(r.w & 1)) { fill_dense<1>(pg, s0, s1, r.z, lid, team); continue; }
+        const uint64_t skip = (s0 - rb) * bw; // bits of the run before this group
+        const uint32_t bit_base = (uint32_t)((int64_t)r.y + (int64_t)(skip >> 3) - base + GROUP_STAGE_PAD) * 8 + (uint32_t)(skip & 7);
+        // Every lane owns eight values that start on an 8-byte boundary of the destination: its
+        // fields lie inside 96 bits from the dword the first one starts in.  At the ragged ends of
+        // the span the same window is cut out (it may start before the first field: the staged
+        // bytes sit GROUP_STAGE_PAD bytes into the buffer) and only the values inside are stored.
+        const uint32_t a = (uint32_t)((uintptr_t)(pg.dst + s0) & 7);
+        for (uint32_t c = lid * 8; c < sn + a; c += team * 8) {
+            const int32_t j0 = (int32_t)c - (int32_t)a;
+            const uint32_t b = bit_base + (uint32_t)(j0 * (int32_t)bw);
+            const uint32_t d = b >> 5;
+            const uint32_t w0 = stage[d], w1 = stage[d + 1], w2 = stage[d + 2];
+            const uint64_t w01 = (uint64_t)w0 | ((uint64_t)w1 << 32);
+            const uint64_t w12 = (uint64_t)w1 | ((uint64_t)w2 << 32);
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t e = 0; e < 8; e++) {
+                const uint32_t off = (b & 31) + e * bw;
+                v[e] = (uint32_t)(off < 32 ? w01 >> off : w12 >> (off - 32)) & mask;
+            }
+            gptr<uint8_t> o = dst + (s0 + (uint64_t)(int64_t)j0);
+            if (j0 >= 0 && (uint32_t)j0 + 8 <= sn) {
+                u32x2 w;
+                w.x = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
+                w.y = v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24);
+                *(gptr<u32x2>)(o) = w;
+            } else {
+#pragma unroll
+                for (uint32_t e = 0; e < 8; e++)
+                    if ((uint32_t)(j0 + (int32_t)e) < sn) o[e] = (uint8_t)v[e]; // unsigned: values before the span fail too
+            }
+        }
+    }
+}
+
 // One-byte outputs (levels, booleans): a whole group of steps at once.  The runs that meet the
 // group are copied to LDS in one go, the packed bytes of all its bit-packed runs in another,
 // and the runs are then expanded one after the other out of LDS: three dependent round trips
 // to memory per workgroup instead of three per run.  Returns false when the group does not
 // fit these buffers; the caller then takes it step by step.
-constexpr uint32_t GROUP_SHORT_RUN = 1024;          // runs of at most this many values are expanded by one wavefront
-constexpr uint32_t GROUP_STAGE_PAD = 16;           // bytes left free before the staged packed data
-
-__device__ inline bool expand_group_bytes(EShared& sh, const DevPage& pg, uint64_t G0, uint32_t GN, uint64_t total,
+__device__ __forceinline__ bool expand_group_bytes(EShared& sh, const DevPage& pg, uint64_t G0, uint32_t GN, uint64_t total,
                                           uint64_t n_runs, uint32_t bw) {
     const uint32_t tid = threadIdx.x;
     gptr<const uint8_t> src = as_global(pg.src);
-    gptr<uint8_t> dst = as_global(pg.dst);
     gptr<const Run> runs = as_global((const Run*)pg.runs);
     if (G0 >= total) return true; // nothing of the stream reaches this group
     const uint32_t GS = total - G0 < GN ? (uint32_t)(total - G0) : GN;
@@ -1099,53 +1153,7 @@ __device__ inline bool expand_group_bytes(EShared& sh, const DevPage& pg, uint64
             *reinterpret_cast<u32x4*>(&sh.stage[(c + GROUP_STAGE_PAD) >> 2]) = *(gptr<const u32x4>)(src + base + c);
     }
     __syncthreads();
-    // Long runs are shared by the whole workgroup, short ones are dealt out to the wavefronts:
-    // no run waits for another, they write disjoint parts of the destination.
-    const uint32_t mask = (1u << bw) - 1;
-    const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (uint32_t k = 0; k < nr; k++) {
-        const u32x4 r = tab[k];
-        const uint64_t rb = r.x, re = rb + (r.w >> 1);
-        const uint64_t s0 = rb > G0 ? rb : G0, s1 = re < G0 + GS ? re : G0 + GS;
-        if (s1 <= s0) continue;
-        const uint32_t sn = (uint32_t)(s1 - s0);
-        const bool shared = sn > GROUP_SHORT_RUN;
-        if (!shared && (k & 3) != wave) continue;
-        const uint32_t lid = shared ? tid : (tid & 63), team = shared ? ET : 64;
-        if (!(r.w & 1)) { fill_dense<1>(pg, s0, s1, r.z, lid, team); continue; }
-        const uint64_t skip = (s0 - rb) * bw; // bits of the run before this group
-        const uint32_t bit_base = (uint32_t)((int64_t)r.y + (int64_t)(skip >> 3) - base + GROUP_STAGE_PAD) * 8 + (uint32_t)(skip & 7);
-        // Every lane owns eight values that start on an 8-byte boundary of the destination: its
-        // fields lie inside 96 bits from the dword the first one starts in.  At the ragged ends of
-        // the span the same window is cut out (it may start before the first field: the staged
-        // bytes sit GROUP_STAGE_PAD bytes into the buffer) and only the values inside are stored.
-        const uint32_t a = (uint32_t)((uintptr_t)(pg.dst + s0) & 7);
-        for (uint32_t c = lid * 8; c < sn + a; c += team * 8) {
-            const int32_t j0 = (int32_t)c - (int32_t)a;
-            const uint32_t b = bit_base + (uint32_t)(j0 * (int32_t)bw);
-            const uint32_t d = b >> 5;
-            const uint32_t w0 = sh.stage[d], w1 = sh.stage[d + 1], w2 = sh.stage[d + 2];
-            const uint64_t w01 = (uint64_t)w0 | ((uint64_t)w1 << 32);
-            const uint64_t w12 = (uint64_t)w1 | ((uint64_t)w2 << 32);
-            uint32_t v[8];
-#pragma unroll
-            for (uint32_t e = 0; e < 8; e++) {
-                const uint32_t off = (b & 31) + e * bw;
-                v[e] = (uint32_t)(off < 32 ? w01 >> off : w12 >> (off - 32)) & mask;
-            }
-            gptr<uint8_t> o = dst + (s0 + (uint64_t)(int64_t)j0);
-            if (j0 >= 0 && (uint32_t)j0 + 8 <= sn) {
-                u32x2 w;
-                w.x = v[0] | (v[1] << 8) | (v[2] << 16) | (v[3] << 24);
-                w.y = v[4] | (v[5] << 8) | (v[6] << 16) | (v[7] << 24);
-                *(gptr<u32x2>)(o) = w;
-            } else {
-#pragma unroll
-                for (uint32_t e = 0; e < 8; e++)
-                    if ((uint32_t)(j0 + (int32_t)e) < sn) o[e] = (uint8_t)v[e]; // unsigned: values before the span fail too
-            }
-        }
-    }
+    expand_runs_bytes(tab, nr, sh.stage, base, pg, G0, GS, bw);
     return true;
 }
 
@@ -1153,27 +1161,10 @@ __device__ inline bool expand_group_bytes(EShared& sh, const DevPage& pg, uint64
 // of its own element type: FAM_RLE_BYTES one byte per element (levels, booleans), FAM_RLE_DICT8 /
 // FAM_RLE_DICT4 through a dictionary of 8- / 4-byte values, FAM_RLE the rest (4-byte values,
 // 12-byte dictionary entries).
+// Tile `tile` of an item's grid (pg.group steps of RLE_TILE values), by one workgroup, out of the run
+// table the index left.  Every return is taken by the whole workgroup.
 template <int FAMILY>
-__global__ __launch_bounds__(ET) __attribute__((amdgpu_waves_per_eu(FAMILY == FAM_RLE_BYTES ? 8 : 4, 8))) void rle_expand_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
-                                                       const uint32_t* __restrict__ items, uint32_t n_items,
-                                                       const uint64_t* __restrict__ tile_prefix,
-                                                       const uint32_t* __restrict__ tile_item) {
-    __shared__ EShared sh;
-    const uint64_t b = blockIdx.x;
-    uint32_t lo = 0;
-    if (tile_item != nullptr) {
-        lo = tile_item[b];
-    } else { // which item does this tile belong to: last i with tile_prefix[i] <= blockIdx.x
-        uint32_t hi = n_items;
-        while (hi - lo > 1) {
-            uint32_t mid = (lo + hi) >> 1;
-            if (tile_prefix[mid] <= b) lo = mid; else hi = mid;
-        }
-    }
-    const uint32_t item = items[lo];
-    const uint64_t tile = b - tile_prefix[lo];
-    const DevPage& pg = pages[item];
-    DevResult* res = &results[item];
+__device__ __forceinline__ void expand_item_tile(EShared& sh, const DevPage& pg, DevResult* res, uint64_t tile) {
     const uint64_t total = res->total;
     const uint64_t n_runs = res->n_runs;
     const uint32_t bw = (uint32_t)res->bw;
@@ -1228,6 +1219,456 @@ __global__ __launch_bounds__(ET) __attribute__((amdgpu_waves_per_eu(FAMILY == FA
     }
 }
 
+template <int FAMILY>
+__global__ __launch_bounds__(ET) __attribute__((amdgpu_waves_per_eu(FAMILY == FAM_RLE_BYTES ? 8 : 4, 8))) void rle_expand_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                       const uint32_t* __restrict__ items, uint32_t n_items,
+                                                       const uint64_t* __restrict__ tile_prefix,
+                                                       const uint32_t* __restrict__ tile_item) {
+    __shared__ EShared sh;
+    const uint64_t b = blockIdx.x;
+    uint32_t lo = 0;
+    if (tile_item != nullptr) {
+        lo = tile_item[b];
+    } else { // which item does this tile belong to: last i with tile_prefix[i] <= blockIdx.x
+        uint32_t hi = n_items;
+        while (hi - lo > 1) {
+            uint32_t mid = (lo + hi) >> 1;
+            if (tile_prefix[mid] <= b) lo = mid; else hi = mid;
+        }
+    }
+    const uint32_t item = items[lo];
+    expand_item_tile<FAMILY>(sh, pages[item], &results[item], b - tile_prefix[lo]);
+}
+
+
+// ------------------------------------------------------ a page per workgroup --
+//
+// Level pages in one pass (rle.go:295-350 decodeBytes, for the widths levels have: 1 to 8 bits).
+// The index + expand pair above goes to memory five times in a row for every tile (the run hint, the
+// runs, the packed bytes, ...) and a lone wavefront follows run headers at about a microsecond
+// each: it issues an instruction every five cycles or so, and a header takes two hundred.  A page
+// of levels is a few kilobytes with a few dozen headers.  Here a workgroup takes a page, window
+// by window (PW_WIN bytes in LDS):
+//   A  every thread works out, for eight byte positions of the window, how far the next header
+//      would be if a header started there (the varint, the run's payload) -- 0 for a position
+//      that cannot start a run the round can use;
+//   B  the first wavefront follows those distances from the known position: the distances of 64
+//      positions sit in one register, a hop is a v_readlane and a select that notes the header's
+//      position in the lane whose turn it is, some forty cycles;
+//   C  a thread per header found reads it in full, a scan over the workgroup gives every run its
+//      first value, the runs go to a table in LDS;
+//   D  all wavefronts expand the table: sixteen values per lane on 16-byte boundaries of the
+//      destination; the runs are looked up in registers (a ballot over 64 table entries).
+// A bit-packed run that reaches past the window is listed piecewise.  Anything the walk does not
+// expect -- a varint over three bytes, a run that runs past the page, more than 2^31-1 values, a
+// width of 0 or above 8 -- ends the attempt: the page is then indexed with rle_index_page and
+// expanded tile by tile by rle_page_retry_kernel, exactly what the kernel pair does, so statuses
+// and the bytes written are the same on every path.
+
+constexpr uint32_t PW_WIN = 2048;                 // bytes of the page resident at a time
+constexpr uint32_t PW_SUBS = PW_WIN / 64;         // stretches of 64 positions
+constexpr uint32_t PW_HDRS = ET;                  // headers followed per round: one per thread
+constexpr uint32_t PW_SLACK = 32;                 // LDS bytes behind the window that reads may touch
+constexpr uint64_t PAGE_RETRY = 0x5041474552455452ull; // DevResult::aux of a page rle_page_kernel left to the retry kernel
+static_assert(PW_WIN == ET * 8, "eight positions per thread");
+
+struct PageShared {
+    uint32_t win[(GROUP_STAGE_PAD + PW_WIN + PW_SLACK) / 4];
+    uint16_t adv[PW_WIN];                         // per position of the window: bytes to the next header, 0: none
+    uint16_t hdr[PW_HDRS];                        // positions (in the window) of the headers the chain holds
+    u32x4 tab[PW_HDRS + 1];                       // the round's runs (Run layout; in_off counts from the page's first byte)
+    uint64_t wsum[ET / 64];
+    // the walk, between rounds.  Positions count from the 16-byte boundary at or before the page's first byte.
+    uint32_t pos;                                 // next header, or next group of the bit-packed run in progress
+    uint32_t pending;                             // groups of eight values that run still holds
+    uint32_t total;                               // values listed so far
+    uint32_t state;                               // 0 going on, 1 page finished, 2 give up
+    uint32_t n_runs;
+    // a round
+    uint32_t n_hdr, cur_end, reason, n_tab;
+};
+static_assert(sizeof(EShared::stage) >= IRING_BYTES, "the retry kernel's index ring fits the stage");
+
+__device__ inline uint32_t pw_uniform(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+__device__ inline void pw_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); } // LDS only: stores stay in flight
+
+// The varint at the head of a0 (up to three bytes: counts below 2^20).
+__device__ inline bool pw_varint(uint32_t a0, uint32_t& k, uint32_t& u) {
+    if (!(a0 & 0x80)) { u = a0 & 0x7f; k = 1; return true; }
+    if (!(a0 & 0x8000)) { u = (a0 & 0x7f) | ((a0 >> 1) & 0x3f80); k = 2; return true; }
+    if (!(a0 & 0x800000)) { u = (a0 & 0x7f) | ((a0 >> 1) & 0x3f80) | ((a0 >> 2) & 0x1fc000); k = 3; return true; }
+    return false;
+}
+
+// Bytes from position p to the next header if a header starts at p (a0: the four bytes there); 0 when
+// the round cannot use a header at p: behind the page's end, too close to the window's end to be
+// read, or not a header the fast path takes (then the walk gives up when it gets there).
+__device__ inline uint32_t pw_advance(uint32_t a0, uint32_t p, uint32_t w_hi, uint32_t end, uint32_t bw) {
+    if (p >= end || (p + 4 > w_hi && w_hi < end)) return 0;
+    uint32_t k, u;
+    if (!pw_varint(a0, k, u) || p + k > end) return 0;
+    const uint32_t count = u >> 1;
+    if (count == 0) return k; // an empty run carries no value byte (rle.go:311-313)
+    if (u & 1) {
+        const uint32_t payload = count * bw; // < 2^23
+        return payload > end - (p + k) ? 0 : k + payload;
+    }
+    return p + k >= end ? 0 : k + 1;
+}
+
+// Sixteen fields of BW bits out of the 128 bits x[0..3] (field i at bit i * BW), one byte each.
+template <uint32_t BW>
+__device__ inline u32x4 page_fields16(const uint32_t (&x)[4]) {
+    if (BW == 8) return u32x4{x[0], x[1], x[2], x[3]};
+    uint32_t o[4];
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) {
+        uint32_t w = 0;
+#pragma unroll
+        for (uint32_t e = 0; e < 4; e++) {
+            const uint32_t bit = (q * 4 + e) * BW, k = bit >> 5, off = bit & 31;
+            uint32_t f;
+            if (off + BW <= 32) f = (x[k] >> off) & ((1u << BW) - 1);
+            else f = __builtin_amdgcn_alignbit(x[(k + 1) & 3], x[k], off) & ((1u << BW) - 1);
+            w |= f << (8 * e);
+        }
+        o[q] = w;
+    }
+    return u32x4{o[0], o[1], o[2], o[3]};
+}
+
+// Sixteen fields of a bit-packed run (packed bytes from page offset e_y on) from its field `first` on; `first`
+// may lie up to 15 fields before the run and the sixteen may reach past its end: the buffer has room
+// on both sides, what is read there is not used.
+__device__ inline u32x4 page_unpack16(const uint32_t* win, uint32_t e_y, int64_t base, int32_t first, uint32_t bw) {
+    const uint32_t b = (uint32_t)((int32_t)(((uint32_t)((int64_t)e_y - base) + GROUP_STAGE_PAD) * 8) + first * (int32_t)bw); // bit in the window buffer
+    const uint32_t d = b >> 5, sft = b & 31;
+    const uint32_t w0 = win[d], w1 = win[d + 1], w2 = win[d + 2], w3 = win[d + 3], w4 = win[d + 4];
+    const uint32_t x[4] = {__builtin_amdgcn_alignbit(w1, w0, sft), __builtin_amdgcn_alignbit(w2, w1, sft),
+                           __builtin_amdgcn_alignbit(w3, w2, sft), __builtin_amdgcn_alignbit(w4, w3, sft)};
+    switch (bw) {
+        case 1: return page_fields16<1>(x);
+        case 2: return page_fields16<2>(x);
+        case 3: return page_fields16<3>(x);
+        case 4: return page_fields16<4>(x);
+        case 5: return page_fields16<5>(x);
+        case 6: return page_fields16<6>(x);
+        case 7: return page_fields16<7>(x);
+        default: return page_fields16<8>(x);
+    }
+}
+
+// Expands the values [G0, G1) that the runs tab[0 .. nr) hold (tab[0] starts at G0, the runs follow
+// one another and reach G1 or beyond) into a dense one-byte destination, sixteen values per lane
+// on 16-byte boundaries of the destination.  64 runs at a time sit in registers, a lane each; a
+// wavefront takes 64 pieces at a time and finds the run of the first by a ballot.  When all 64
+// lie inside that run -- most values of a level stream belong to long runs -- every lane stores a
+// splat or unpacks its sixteen fields without looking anything up; otherwise every lane finds
+// the run of its piece in the table, and a piece that meets several runs, or the ragged ends of a
+// stretch, goes value by value.
+__device__ inline void page_expand(const u32x4* tab, uint32_t nr, const uint32_t* win, int64_t base, const DevPage& pg, uint32_t G0,
+                                   uint32_t G1, uint32_t bw) {
+    const uint32_t lane = threadIdx.x & 63, wave = pw_uniform(threadIdx.x >> 6);
+    gptr<uint8_t> dst = as_global(pg.dst);
+    const uint32_t a = (uint32_t)((uintptr_t)pg.dst & 15); // piece c holds the values [16 c - a, 16 c - a + 16)
+    for (uint32_t rb = 0; rb < nr; rb += 64) {
+        u32x4 mine = u32x4{0xffffffffu, 0, 0, 0};
+        if (rb + lane < nr) mine = tab[rb + lane];
+        const uint32_t nb = nr - rb < 64 ? nr - rb : 64;
+        const uint32_t B0 = rb == 0 ? G0 : pw_uniform(mine.x);
+        const uint32_t last_end = (uint32_t)__builtin_amdgcn_readlane((int)(mine.x + (mine.w >> 1)), (int)(nb - 1));
+        const uint32_t B1 = last_end < G1 ? last_end : G1; // this stretch of runs holds [B0, B1)
+        if (B1 <= B0) break;
+        const uint32_t c_lo = (B0 + a) >> 4, c_hi = (B1 + a + 15) >> 4;
+        for (uint32_t c0 = c_lo + wave * 64; c0 < c_hi; c0 += (ET / 64) * 64) {
+            const uint32_t c1 = c0 + 64 < c_hi ? c0 + 64 : c_hi;
+            const uint32_t q_lo = c0 * 16 > B0 + a ? c0 * 16 - a : B0; // first value of these pieces inside the stretch
+            const unsigned long long le = __ballot(mine.x <= q_lo);
+            const uint32_t r = (uint32_t)__popcll(le) - 1;              // lane that holds the run of q_lo
+            const uint32_t e_x = (uint32_t)__builtin_amdgcn_readlane((int)mine.x, (int)r);
+            const uint32_t e_w = (uint32_t)__builtin_amdgcn_readlane((int)mine.w, (int)r);
+            const bool whole = c0 * 16 >= B0 + a && c1 == c0 + 64 && c1 * 16 - a <= B1; // 64 full pieces
+            const uint32_t c = c0 + lane;
+            if (whole && c1 * 16 - a <= e_x + (e_w >> 1)) {
+                const uint32_t P = c * 16 - a;
+                u32x4 v;
+                if (e_w & 1) {
+                    v = page_unpack16(win, (uint32_t)__builtin_amdgcn_readlane((int)mine.y, (int)r), base, (int32_t)(P - e_x), bw);
+                } else {
+                    const uint32_t w = ((uint32_t)__builtin_amdgcn_readlane((int)mine.z, (int)r) & 0xff) * 0x01010101u;
+                    v = u32x4{w, w, w, w};
+                }
+                *(gptr<u32x4>)(dst + P) = v;
+                continue;
+            }
+            if (c >= c1) continue;
+            // ---- the lane's own piece: [p0, p1) of it lie inside the stretch ----
+            const int64_t Ps = (int64_t)c * 16 - a;
+            const uint32_t p0 = Ps < (int64_t)B0 ? B0 : (uint32_t)Ps, p1 = Ps + 16 > (int64_t)B1 ? B1 : (uint32_t)(Ps + 16);
+            if (p1 <= p0) continue;
+            uint32_t rl = rb + r;
+            while (rl + 1 < rb + nb && tab[rl + 1].x <= p0) rl++;
+            // what each run that meets the piece puts into its sixteen bytes, merged under byte masks
+            u32x4 acc = u32x4{0, 0, 0, 0};
+            for (uint32_t q = p0;;) {
+                const u32x4 e = tab[rl];
+                const uint32_t re = e.x + (e.w >> 1), q1 = re < p1 ? re : p1; // this run holds [q, q1) of the piece
+                u32x4 v;
+                if (e.w & 1) v = page_unpack16(win, e.y, base, (int32_t)(Ps - (int64_t)e.x), bw);
+                else { const uint32_t w = (e.z & 0xff) * 0x01010101u; v = u32x4{w, w, w, w}; }
+                const uint32_t lo = (uint32_t)((int64_t)q - Ps), hi = (uint32_t)((int64_t)q1 - Ps); // bytes [lo, hi) of the piece
+                uint32_t m[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4; j++) {
+                    const uint32_t l4 = lo > 4 * j ? (lo - 4 * j < 4 ? lo - 4 * j : 4) : 0, h4 = hi > 4 * j ? (hi - 4 * j < 4 ? hi - 4 * j : 4) : 0;
+                    const uint32_t below_h = h4 == 4 ? 0xffffffffu : (1u << (8 * h4)) - 1, below_l = l4 == 4 ? 0xffffffffu : (1u << (8 * l4)) - 1;
+                    m[j] = below_h & ~below_l;
+                }
+                acc.x |= v.x & m[0]; acc.y |= v.y & m[1]; acc.z |= v.z & m[2]; acc.w |= v.w & m[3];
+                q = q1;
+                if (q >= p1) break;
+                rl++; // every listed run holds a value, and the runs cover the stretch
+            }
+            if (p1 - p0 == 16) {
+                *(gptr<u32x4>)(dst + p0) = acc;
+            } else {
+                const uint32_t words[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+                for (uint32_t i = 0; i < 16; i++) {
+                    const int64_t pi = Ps + i;
+                    if (pi >= (int64_t)p0 && pi < (int64_t)p1) dst[pi] = (uint8_t)(words[i >> 2] >> (8 * (i & 3)));
+                }
+            }
+        }
+    }
+}
+
+// Phase B: follows the distances in sh.adv from window position `cur`; notes the headers it meets
+// in sh.hdr.  One wavefront; everything but the registers of distances and positions is uniform.
+// Positions at or behind the window's last byte hold no distance: the walk ends when it gets there.
+__device__ inline void page_chase(PageShared& sh, uint32_t cur, uint32_t w_lo, uint32_t w_hi, uint32_t end) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t size = w_hi - w_lo;
+    uint32_t av[PW_SUBS];
+#pragma unroll
+    for (uint32_t s = 0; s < PW_SUBS; s++) av[s] = s * 64 < size ? (uint32_t)sh.adv[s * 64 + lane] : 0u;
+    uint32_t h = 0, n = 0;
+    bool zero = false, full = false;
+#pragma unroll
+    for (uint32_t s = 0; s < PW_SUBS; s++) {
+        if (zero || full || cur >= size) break;
+        while (cur < 64 * (s + 1)) { // (cur >= 64 s: the walk only moves forward)
+            if (cur >= size) break;
+            const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)av[s], (int)(cur & 63));
+            if (d == 0) { zero = true; break; }
+            if (n == PW_HDRS) { full = true; break; }
+            h = lane == (n & 63) ? cur : h;
+            n++;
+            cur += d;
+            if ((n & 63) == 0) sh.hdr[n - 64 + lane] = (uint16_t)h;
+        }
+    }
+    if (n & 63) sh.hdr[(n & ~63u) + lane] = (uint16_t)h;
+    const uint32_t p = w_lo + cur;
+    uint32_t reason = 0; // 0: the next round goes on from p, 1: p is the page's end, 2: p holds nothing the fast path takes
+    if (p >= end) reason = 1;
+    else if (zero && !(p + 4 > w_hi && w_hi < end)) reason = 2;
+    if (lane == 0) { sh.n_hdr = n; sh.cur_end = p; sh.reason = reason; }
+}
+
+__global__ __launch_bounds__(ET) __attribute__((amdgpu_waves_per_eu(8, 8))) void rle_page_kernel(const DevPage* __restrict__ pages,
+                                                                                                 DevResult* __restrict__ results,
+                                                                                                 const uint32_t* __restrict__ items) {
+    __shared__ PageShared sh;
+#ifdef PQD_PAGE_TIMING2
+    const uint64_t t_entry = __builtin_readcyclecounter();
+#endif
+    const uint32_t item = items[blockIdx.x];
+    const DevPage& pg = pages[item];
+    DevResult* res = &results[item];
+    const uint32_t tid = threadIdx.x, wave = pw_uniform(tid >> 6), lane = tid & 63;
+    const uint32_t bw = (uint32_t)pg.bit_width;
+    const bool dense = pg.kind == PQD_KIND_LEVELS && pg.encoding == PQD_ENC_RLE && pg.elem_width == 1 && pg.dst_stride <= 1 && !pg.fused;
+    if (dense && bw >= 1 && bw <= 8 && pg.src_len <= 0x7ff00000ull) {
+        const uint32_t mis = (uint32_t)((uintptr_t)pg.src & 15);
+        gptr<const uint8_t> base = as_global(pg.src) - mis;
+        const uint32_t end = mis + (uint32_t)pg.src_len;
+        const uint64_t limit64 = pg.num_values >= 0 && (uint64_t)pg.num_values < pg.dst_cap ? (uint64_t)pg.num_values : pg.dst_cap;
+        const uint32_t limit = limit64 > MAX_TOTAL ? MAX_TOTAL : (uint32_t)limit64; // values that may be written
+        if (tid == 0) { sh.pos = mis; sh.pending = 0; sh.total = 0; sh.state = 0; sh.n_runs = 0; }
+        pw_barrier();
+        uint32_t state;
+#ifdef PQD_PAGE_TIMING
+        uint64_t t_load = 0, t_walk = 0, t_exp = 0, t0 = __builtin_readcyclecounter(), t1;
+#define PQD_TICK(acc) t1 = __builtin_readcyclecounter(); acc += t1 - t0; t0 = t1;
+#else
+#define PQD_TICK(acc)
+#endif
+        for (;;) {
+            const uint32_t pos = sh.pos, G0 = sh.total, pending = sh.pending;
+            const uint32_t w_lo = pos & ~15u;
+            const uint32_t w_hi = w_lo + PW_WIN < end ? w_lo + PW_WIN : end;
+            // ---- the window: aligned chunks that hold a byte of the page ----
+            if (tid < (PW_WIN + PW_SLACK) / 16 && w_lo + tid * 16 < end)
+                *reinterpret_cast<u32x4*>(&sh.win[(GROUP_STAGE_PAD + tid * 16) >> 2]) = *(gptr<const u32x4>)(base + w_lo + tid * 16);
+            // the part of a bit-packed run in progress that the window holds
+            const uint32_t room = (w_hi - pos) / bw;
+            const uint32_t gp = pending < room ? pending : room, pend_left = pending - gp;
+            const uint32_t cur0 = pos + gp * bw, pend_vals = gp * 8;
+            pw_barrier();
+            // ---- A: the distance to the next header, at every position the window holds ----
+            {
+                const uint32_t* w = sh.win + GROUP_STAGE_PAD / 4;
+                for (uint32_t rel = tid; rel < w_hi - w_lo; rel += ET) {
+                    const uint32_t dw = rel >> 2;
+                    const uint32_t a0 = __builtin_amdgcn_alignbit(w[dw + 1], w[dw], (rel & 3) * 8);
+                    const uint32_t x = pw_advance(a0, w_lo + rel, w_hi, end, bw);
+                    sh.adv[rel] = (uint16_t)(x < 0xffffu ? x : 0xffffu); // anything this long leaves the window
+                }
+            }
+            pw_barrier();
+            PQD_TICK(t_load)
+            // ---- B: the chain of headers ----
+            if (wave == 0) {
+                if (pend_left > 0) { // the run in progress fills the window
+                    if (lane == 0) { sh.n_hdr = 0; sh.cur_end = cur0; sh.reason = 0; }
+                } else {
+                    page_chase(sh, cur0 - w_lo, w_lo, w_hi, end);
+                }
+            }
+            pw_barrier();
+            PQD_TICK(t_walk)
+            // ---- C: the headers in full, their runs' first values, the table ----
+            const uint32_t n_hdr = sh.n_hdr;
+            uint32_t nvals = 0, listed = 0, in_off = 0, value = 0, kind = 0, more = 0, next_pos = 0;
+            if (tid < n_hdr) {
+                const uint32_t rel = sh.hdr[tid], dw = rel >> 2;
+                const uint32_t* w = sh.win + GROUP_STAGE_PAD / 4;
+                const uint32_t a0 = __builtin_amdgcn_alignbit(w[dw + 1], w[dw], (rel & 3) * 8);
+                uint32_t k = 1, u = 0;
+                pw_varint(a0, k, u); // it parsed in phase A
+                const uint32_t count = u >> 1, in_abs = w_lo + rel + k;
+                in_off = in_abs - mis;
+                if (count == 0) {
+                } else if (u & 1) {
+                    const uint32_t fit = in_abs < w_hi ? (w_hi - in_abs) / bw : 0;
+                    const uint32_t g = count < fit ? count : fit;
+                    nvals = g * 8; listed = g > 0; kind = 1;
+                    more = count - g; next_pos = in_abs + g * bw; // more > 0: the rest of the run is the next round's
+                } else {
+                    nvals = count; listed = 1; value = (a0 >> (8 * k)) & 0xff;
+                }
+            }
+            const uint64_t packed = ((uint64_t)listed << 40) | nvals;
+            const uint64_t incl = wave_inclusive_scan<uint64_t>(packed);
+            if (lane == 63) sh.wsum[wave] = incl;
+            pw_barrier();
+            uint64_t before = 0, all = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < ET / 64; w++) {
+                const uint64_t t = sh.wsum[w];
+                if (w < wave) before += t;
+                all += t;
+            }
+            const uint64_t excl = before + incl - packed;
+            const uint32_t has_pend = gp > 0 ? 1u : 0u;
+            if (listed) {
+                u32x4 e;
+                e.x = G0 + pend_vals + (uint32_t)(excl & 0xffffffffffull);
+                e.y = in_off; e.z = value; e.w = (nvals << 1) | kind;
+                sh.tab[has_pend + (uint32_t)(excl >> 40)] = e;
+            }
+            if (tid == 0 && has_pend) {
+                u32x4 e;
+                e.x = G0; e.y = pos - mis; e.z = 0; e.w = (pend_vals << 1) | 1u;
+                sh.tab[0] = e;
+            }
+            const uint64_t G1_64 = (uint64_t)G0 + pend_vals + (all & 0xffffffffffull);
+            const uint32_t nr = has_pend + (uint32_t)(all >> 40);
+            if (tid == (n_hdr > 0 ? n_hdr - 1 : 0)) { // one thread moves the walk on
+                uint32_t st = sh.reason, np = sh.cur_end, npend = 0;
+                if (n_hdr == 0 && pend_left > 0) { np = cur0; npend = pend_left; st = 0; }
+                else if (n_hdr > 0 && more > 0) { np = next_pos; npend = more; st = 0; }
+                if (G1_64 > MAX_TOTAL) st = 2;
+                sh.pos = np; sh.pending = npend; sh.total = (uint32_t)G1_64; sh.state = st; sh.n_runs += n_hdr;
+            }
+            pw_barrier();
+            state = sh.state;
+            if (state == 2) break;
+            // ---- D: the values ----
+            const uint32_t G1 = (uint32_t)G1_64;
+            if (G0 < limit && G1 > G0) page_expand(sh.tab, nr, sh.win, (int64_t)w_lo - (int64_t)mis, pg, G0, G1 < limit ? G1 : limit, bw);
+            if (state == 1) break;
+            pw_barrier(); // the window and the table are rewritten
+            PQD_TICK(t_exp)
+        }
+        PQD_TICK(t_exp)
+        if (state == 1) {
+            if (tid == 0) {
+                const uint64_t total = sh.total;
+                const uint64_t n_out = pg.num_values >= 0 && (uint64_t)pg.num_values < total ? (uint64_t)pg.num_values : total;
+                const bool too_small = n_out > pg.dst_cap;
+                const uint64_t w = too_small ? pg.dst_cap : n_out;
+                res->status = too_small ? PQD_ERR_DST_TOO_SMALL : PQD_OK;
+                res->arg = too_small ? (int64_t)n_out : 0;
+                res->bw = (int32_t)bw;
+                res->out_values = w;
+                res->out_bytes = w;
+                res->consumed = sh.pos - mis;
+                res->n_runs = sh.n_runs < pg.runs_cap ? sh.n_runs : pg.runs_cap;
+                res->total = total;
+                res->aux = ~0ull;
+#ifdef PQD_PAGE_TIMING
+                res->arg = (int64_t)t_walk;
+                res->consumed = (t_load << 32) | (t_exp & 0xffffffffull);
+#endif
+#ifdef PQD_PAGE_TIMING2
+                res->arg = (int64_t)t_entry;
+                res->consumed = __builtin_readcyclecounter();
+#endif
+            }
+            return;
+        }
+    }
+    // ---- everything else is left to rle_page_retry_kernel ----
+    if (tid == 0) res->aux = PAGE_RETRY;
+}
+
+// The pages rle_page_kernel gave up on: the page's run table by one wavefront, then tile by tile,
+// as the index + expand kernels do it (a kernel of its own: the index needs twice the registers).
+// Usually there are none, so the grid is small: workgroup b looks at the pages b, b + grid, ...,
+// a thread per page, and takes the flagged ones in turn.
+__global__ __launch_bounds__(ET) void rle_page_retry_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                            const uint32_t* __restrict__ items, uint32_t n_items) {
+    __shared__ EShared sh;
+    __shared__ ICtl ctl;
+    __shared__ unsigned long long flagged[ET / 64];
+    for (uint32_t k0 = blockIdx.x; k0 < n_items; k0 += gridDim.x * ET) {
+        const uint32_t k = k0 + threadIdx.x * gridDim.x;
+        const bool retry = k < n_items && as_global((const DevResult*)&results[items[k]])->aux == PAGE_RETRY;
+        const unsigned long long m = __ballot(retry);
+        if ((threadIdx.x & 63) == 0) flagged[threadIdx.x >> 6] = m;
+        __syncthreads();
+        for (uint32_t w = 0; w < ET / 64; w++) {
+            unsigned long long todo = flagged[w];
+            while (todo) {
+                const uint32_t t = w * 64 + (uint32_t)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                const uint32_t item = items[k0 + t * gridDim.x];
+                const DevPage& pg = pages[item];
+                DevResult* res = &results[item];
+                if (threadIdx.x < 64) rle_index_page<true>(sh.stage, ctl, pg, res, threadIdx.x);
+                __syncthreads();
+                const uint32_t n_tiles = (pg.n_steps + pg.group - 1) / pg.group;
+                for (uint32_t tile = 0; tile < n_tiles; tile++) {
+                    expand_item_tile<FAM_RLE_BYTES>(sh, pg, res, tile);
+                    __syncthreads();
+                }
+            }
+        }
+        __syncthreads(); // the flags are rewritten
+    }
+}
 
 // ------------------------------------------------- dictionary held in LDS --
 //
@@ -2206,6 +2647,12 @@ if (plan.slices > 1) {
     if (elem == 8) { if (plan.part) PQD_LDS_LAUNCH(8, true); else PQD_LDS_LAUNCH(8, false); }
     else { if (plan.part) PQD_LDS_LAUNCH(4, true); else PQD_LDS_LAUNCH(4, false); }
 #undef PQD_LDS_LAUNCH
+}
+
+void launch_rle_pages(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, hipStream_t stream) {
+    if (n_items == 0) return;
+    hipLaunchKernelGGL(rle_page_kernel, dim3(n_items), dim3(ET), 0, stream, pages, results, items);
+    hipLaunchKernelGGL(rle_page_retry_kernel, dim3(n_items < 256 ? n_items : 256), dim3(ET), 0, stream, pages, results, items, n_items);
 }
 
 void launch_rle_index(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, const uint32_t* pk_flag,

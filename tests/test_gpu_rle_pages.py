@@ -1,0 +1,157 @@
+"""GPU: repetition / definition level pages (RLE hybrid, rle.go:295-350) through both of their
+paths -- a workgroup per page that follows the run headers and expands the runs in one launch
+(the default), and the index + expand kernels every other RLE page takes (PQD_RLE_PAGE=0) --
+against the CPU checker: same values, statuses, status arguments and value counts.  The shapes
+aim at the page kernel's seams: pages longer than its window, bit-packed runs longer than the
+window, more runs inside a window than its table lists, varints it leaves to the retry kernel,
+damaged pages, a destination that is too small, pages cut to num_values."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import pqoracle as O
+from tests.gpu_util import assert_same, pkg, spec
+from tests.test_gpu_rle import _levels_cases, _runs_of
+
+pytestmark = pytest.mark.gpu
+
+_ctxs = {}
+
+
+def _ctx(mode):
+    if mode not in _ctxs:
+        old = os.environ.get("PQD_RLE_PAGE")
+        os.environ["PQD_RLE_PAGE"] = "2" if mode == "page" else "0"
+        try:
+            _ctxs[mode] = pkg().Context(0)
+        finally:
+            if old is None:
+                os.environ.pop("PQD_RLE_PAGE", None)
+            else:
+                os.environ["PQD_RLE_PAGE"] = old
+    return _ctxs[mode]
+
+
+def _decode(mode, specs, grow=True):
+    from parquet_go_amd.runtime import decode_pages
+    return decode_pages(_ctx(mode), specs, grow=grow)
+
+
+def _uvarint(v):
+    out = bytearray()
+    while v >= 0x80:
+        out.append((v & 0x7F) | 0x80)
+        v >>= 7
+    out.append(v)
+    return bytes(out)
+
+
+MODES = ("page", "kernels")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_level_tables_and_mixed_runs(mode):
+    P = pkg()
+    cases = _levels_cases(np.random.default_rng(3))
+    outs = _decode(mode, [spec(P.ENC.RLE, P.KIND.LEVELS, enc, bit_width=bw, misalign=k % 16) for k, (_, bw, enc) in enumerate(cases)])
+    for (label, bw, enc), out in zip(cases, outs):
+        assert_same(out, O.rle_decode_levels(enc, bw), np.uint8, f"{mode}-{label}")
+
+
+def _seam_cases(rng):
+    cases = []  # (label, bit width, bytes)
+    for bw, short, long_ in ((1, 2, 40), (2, 1.2, 9), (3, 3, 60), (5, 8, 3000), (7, 1.5, 20), (8, 4, 100)):
+        v = _runs_of(rng, 300_000, 1 << bw, short, long_).astype(np.uint8)
+        cases.append((f"go-bw{bw}", bw, O.rle_encode_levels(v, bw)))
+        cases.append((f"mr-bw{bw}", bw, O.rle_encode_levels_mr(v, bw)))
+    for bw in (1, 3, 8):  # no runs at all: one bit-packed run of many windows
+        v = rng.integers(0, 1 << bw, size=200_000, dtype=np.uint8)
+        cases.append((f"one-bit-packed-run-bw{bw}", bw, O.rle_encode_levels(v, bw)))
+    # runs of eight equal values, two bytes each: four thousand to a window
+    cases.append(("short-runs", 2, b"".join(bytes([8 << 1, k & 3]) for k in range(30_000))))
+    # bit-packed runs of exactly the window, and one byte more or less, between short runs
+    for groups in (8192 // 3, 8192 // 3 + 1, 3 * 8192 // 3 - 1, 20_000):
+        body = bytes(rng.integers(0, 256, size=3 * groups, dtype=np.uint8))
+        cases.append((f"bit-packed-{groups}", 3, b"\x06\x05" * 5 + _uvarint((groups << 1) | 1) + body + b"\x08\x02" * 700))
+    # empty runs, scattered
+    parts = []
+    for k in range(9000):
+        parts.append(b"\x00" if k % 3 == 0 else (bytes([2 * (1 + k % 50)]) + bytes([k % 4])))
+        if k % 500 == 499:
+            parts.append(bytes([(8 << 1) | 1]) + bytes(rng.integers(0, 256, size=8 * 2, dtype=np.uint8)))
+    cases.append(("empty-runs", 2, b"".join(parts)))
+    # counts that need a varint of four or five bytes (left to the retry kernel), between ordinary runs
+    cases.append(("long-varints", 1, b"\x06\x01" * 100 + _uvarint(3_000_000 << 1) + b"\x01" + b"\x08\x00" * 50 + _uvarint((300_000 << 1) | 1) + bytes(300_000)))
+    # damaged pages
+    good = O.rle_encode_levels_mr(_runs_of(rng, 200_000, 8, 2, 30).astype(np.uint8), 3)
+    cases.append(("truncated", 3, good[: len(good) - 1]))
+    cases.append(("truncated-early", 3, good[:9]))
+    cases.append(("bad-varint", 3, good[:30_000] + b"\x80" * 11 + good[30_000:]))
+    cases.append(("bit-packed-overruns", 3, good[:25_000] + b"\xff\xff\x03" + good[25_000:40_000]))
+    cases.append(("no-value-byte", 3, good + b"\x10"))
+    cases.append(("width-0", 0, b"\x10" * 40))
+    cases.append(("width-9", 9, b"\x10\x01"))
+    cases.append(("empty", 4, b""))
+    return cases
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_seams(mode):
+    P = pkg()
+    cases = _seam_cases(np.random.default_rng(17))
+    outs = _decode(mode, [spec(P.ENC.RLE, P.KIND.LEVELS, enc, bit_width=bw, misalign=(5 * k) % 16) for k, (_, bw, enc) in enumerate(cases)])
+    for (label, bw, enc), out in zip(cases, outs):
+        want = O.rle_decode_levels(enc, bw)
+        assert_same(out, want, np.uint8, f"{mode}-{label}", values=want.status == 0)
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_too_many_values(mode):
+    # the one limit the reference does not have: a page decodes to at most 2**31 - 1 values here
+    P = pkg()
+    huge = bytes([0xfe, 0xff, 0xff, 0xff, 0x07, 0x01])  # one run of 2**30 - 1 values
+    small = bytes([0xfe, 0xff, 0x7f, 0x01])             # 2**20 - 1 values, a three-byte varint
+    outs = _decode(mode, [spec(P.ENC.RLE, P.KIND.LEVELS, b"\x06\x01" * 9000 + huge * 3, bit_width=1, dst_cap=1 << 16),
+                          spec(P.ENC.RLE, P.KIND.LEVELS, small * 2100, bit_width=1, dst_cap=1 << 16)], grow=False)
+    assert outs[0].status == P.STATUS.RUN_TOO_LARGE
+    assert outs[1].status == P.STATUS.RUN_TOO_LARGE
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_cut_and_capacity(mode):
+    P = pkg()
+    rng = np.random.default_rng(23)
+    v = _runs_of(rng, 150_000, 4, 3, 500).astype(np.uint8)
+    enc = O.rle_encode_levels(v, 2)
+    full = O.rle_decode_levels(enc, 2).values
+    specs, wants = [], []
+    for nv in (0, 1, 7, 4096, 70_001, full.size - 1, full.size, full.size + 5):  # column.go:940-945: the caller keeps num_values levels
+        specs.append(spec(P.ENC.RLE, P.KIND.LEVELS, enc, bit_width=2, num_values=nv, dst_cap=nv + 3))
+        wants.append((0, min(nv, full.size)))
+    for cap in (1, 5, 8191, 100_000):
+        specs.append(spec(P.ENC.RLE, P.KIND.LEVELS, enc, bit_width=2, dst_cap=cap))
+        wants.append((P.STATUS.DST_TOO_SMALL, cap))
+    specs.append(spec(P.ENC.RLE, P.KIND.LEVELS, enc, bit_width=2, num_values=90_000, dst_cap=60_000))
+    wants.append((P.STATUS.DST_TOO_SMALL, 60_000))
+    outs = _decode(mode, specs, grow=False)
+    for k, (out, (st, n)) in enumerate(zip(outs, wants)):
+        assert out.status == st and out.out_values == n, (mode, k, out.status, out.arg, out.out_values)
+        assert np.array_equal(out.data[:n], full[:n]), (mode, k)
+        if st != 0:
+            assert out.arg == (90_000 if k == len(wants) - 1 else full.size), (mode, k, out.arg)
+
+
+def test_many_pages_in_a_batch():
+    # a row group's worth of level pages: the page kernel's grid is the family's item list
+    P = pkg()
+    rng = np.random.default_rng(29)
+    specs, wants = [], []
+    for k in range(300):
+        bw = 1 + k % 4
+        v = _runs_of(rng, int(rng.integers(1, 40_000)), 1 << bw, 2 + k % 5, 30 * (1 + k % 9)).astype(np.uint8)
+        enc = O.rle_encode_levels(v, bw) if k % 2 else O.rle_encode_levels_mr(v, bw)
+        specs.append(spec(P.ENC.RLE, P.KIND.LEVELS, enc, bit_width=bw, misalign=k % 16))
+        wants.append(O.rle_decode_levels(enc, bw))
+    for k, (out, want) in enumerate(zip(_decode("page", specs), wants)):
+        assert_same(out, want, np.uint8, f"page {k}")
