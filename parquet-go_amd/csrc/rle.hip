@@ -1252,9 +1252,10 @@ __global__ __launch_bounds__(ET) __attribute__((amdgpu_waves_per_eu(FAMILY == FA
 //   A  every thread works out, for eight byte positions of the window, how far the next header
 //      would be if a header started there (the varint, the run's payload) -- 0 for a position
 //      that cannot start a run the round can use;
-//   B  the first wavefront follows those distances from the known position: the distances of 64
-//      positions sit in one register, a hop is a v_readlane and a select that notes the header's
-//      position in the lane whose turn it is, some forty cycles;
+//   B  the first wavefront follows those distances from the known position: the distances of the
+//      64 positions around it sit in one register, a hop inside them is a v_readlane and a
+//      select that notes the header's position in the lane whose turn it is, a hop out of them
+//      one LDS read more;
 //   C  a thread per header found reads it in full, a scan over the workgroup gives every run its
 //      first value, the runs go to a table in LDS;
 //   D  all wavefronts expand the table: sixteen values per lane on 16-byte boundaries of the
@@ -1266,7 +1267,6 @@ __global__ __launch_bounds__(ET) __attribute__((amdgpu_waves_per_eu(FAMILY == FA
 // and the bytes written are the same on every path.
 
 constexpr uint32_t PW_WIN = 2048;                 // bytes of the page resident at a time
-constexpr uint32_t PW_SUBS = PW_WIN / 64;         // stretches of 64 positions
 constexpr uint32_t PW_HDRS = ET;                  // headers followed per round: one per thread
 constexpr uint32_t PW_SLACK = 32;                 // LDS bytes behind the window that reads may touch
 constexpr uint64_t PAGE_RETRY = 0x5041474552455452ull; // DevResult::aux of a page rle_page_kernel left to the retry kernel
@@ -1445,21 +1445,18 @@ __device__ inline void page_expand(const u32x4* tab, uint32_t nr, const uint32_t
 
 // Phase B: follows the distances in sh.adv from window position `cur`; notes the headers it meets
 // in sh.hdr.  One wavefront; everything but the registers of distances and positions is uniform.
-// Positions at or behind the window's last byte hold no distance: the walk ends when it gets there.
+// The distances of the 64 positions around the walk's position sit in one register (a lane
+// each): hops inside that stretch are a v_readlane away, a hop out of it costs one LDS read.
 __device__ inline void page_chase(PageShared& sh, uint32_t cur, uint32_t w_lo, uint32_t w_hi, uint32_t end) {
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t size = w_hi - w_lo;
-    uint32_t av[PW_SUBS];
-#pragma unroll
-    for (uint32_t s = 0; s < PW_SUBS; s++) av[s] = s * 64 < size ? (uint32_t)sh.adv[s * 64 + lane] : 0u;
     uint32_t h = 0, n = 0;
     bool zero = false, full = false;
-#pragma unroll
-    for (uint32_t s = 0; s < PW_SUBS; s++) {
-        if (zero || full || cur >= size) break;
-        while (cur < 64 * (s + 1)) { // (cur >= 64 s: the walk only moves forward)
-            if (cur >= size) break;
-            const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)av[s], (int)(cur & 63));
+    while (!zero && !full && cur < size) {
+        const uint32_t seg = cur >> 6;
+        const uint32_t av = sh.adv[seg * 64 + lane]; // (positions at or behind the window's last byte are never looked at)
+        while ((cur >> 6) == seg && cur < size) {
+            const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)av, (int)(cur & 63));
             if (d == 0) { zero = true; break; }
             if (n == PW_HDRS) { full = true; break; }
             h = lane == (n & 63) ? cur : h;
