@@ -155,3 +155,38 @@ def test_many_pages_in_a_batch():
         wants.append(O.rle_decode_levels(enc, bw))
     for k, (out, want) in enumerate(zip(_decode("page", specs), wants)):
         assert_same(out, want, np.uint8, f"page {k}")
+
+
+@pytest.mark.parametrize("mode", MODES)
+def test_destinations_at_every_alignment(mode):
+    # the page kernel writes sixteen bytes per lane on 16-byte boundaries of the destination: the ragged
+    # ends of every stretch, at every alignment, with canaries on both sides
+    import torch
+    from parquet_go_amd.runtime import Batch, DeviceBuffer, to_device
+    P = pkg()
+    rng = np.random.default_rng(31)
+    pages, keep = [], []
+    for k in range(48):
+        bw = 1 + k % 8
+        n = int(rng.integers(1, 9000)) if k % 3 else int(rng.integers(20_000, 70_000))
+        v = _runs_of(rng, n, 1 << bw, 2 + k % 4, 15 * (1 + k % 7)).astype(np.uint8)
+        enc = O.rle_encode_levels(v, bw) if k % 2 else O.rle_encode_levels_mr(v, bw)
+        want = O.rle_decode_levels(enc, bw).values
+        src = to_device(enc, misalign=(7 * k) % 16)
+        buf = DeviceBuffer(want.size + 64, misalign=0, fill=0xA5)
+        a = 16 + k % 16  # destination starts a bytes into the buffer
+        p = P.Page()
+        p.src, p.src_len, p.dst, p.dst_cap = src.ptr, len(enc), buf.ptr + a, want.size
+        p.bit_width, p.num_values = bw, -1
+        p.encoding, p.kind = P.ENC.RLE, P.KIND.LEVELS
+        pages.append(p)
+        keep.append((src, buf, a, want))
+    b = Batch(_ctx(mode), pages)
+    stream = torch.cuda.current_stream(0).cuda_stream
+    b.launch(stream)
+    res = b.finish(stream)
+    for k, (src, buf, a, want) in enumerate(keep):
+        raw = buf.numpy()
+        assert res[k].status == 0 and res[k].out_values == want.size, (mode, k, res[k].status)
+        assert np.array_equal(raw[a: a + want.size], want), (mode, k)
+        assert (raw[:a] == 0xA5).all() and (raw[a + want.size:] == 0xA5).all(), (mode, k)
