@@ -479,9 +479,19 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
     if (ctx->dict_lds != 0) {
         for (int32_t from : {FAM_RLE_DICT8, FAM_RLE_DICT4}) {
             const int32_t to = from == FAM_RLE_DICT8 ? FAM_RLE_LDS8 : FAM_RLE_LDS4;
+            // A page well shorter than its values bit-packed in one run is full of run headers: its tiles meet several
+            // runs each, which the persistent kernel decodes a wavefront per tile and the tile-per-workgroup kernel
+            // three times as fast (unless the choice is forced)
+            auto full_of_runs = [&](const DevPage& d) {
+                if (ctx->dict_lds == 2 || d.num_values <= 0 || d.dict_len == 0) return false;
+                uint64_t width = 0;
+                for (uint64_t m = d.dict_len - 1; m; m >>= 1) width++;
+                const uint64_t packed = ((uint64_t)d.num_values * width + 7) / 8;
+                return d.src_len >= RLE_CHUNKED_MIN_BYTES_FEW && d.src_len * 10 < packed * 9;
+            };
             auto candidate = [&](const DevPage& d) {
                 return d.family == from && d.fused && (d.dst_stride == 0 || d.dst_stride == d.elem_width) &&
-                       d.dict_len * (uint64_t)d.elem_width <= ctx->dict_lds_max_bytes;
+                       d.dict_len * (uint64_t)d.elem_width <= ctx->dict_lds_max_bytes && !full_of_runs(d);
             };
             // What the path costs: every persistent workgroup copies the dictionary of every stretch of pages
             // it meets into LDS.  It pays while those copies stay below the bytes decoded.
