@@ -63,6 +63,27 @@ __device__ inline uint32_t bitpacked_value(gptr<const uint8_t> src, uint64_t n, 
 }
 
 // grid.x = pages of the family, grid.y = tile slots; a tile is MT * 16 values.
+// Sixteen fields of BW bits, the first at the top of the 128-bit number x[3] .. x[0], one byte each (the shifts
+// are compile-time constants: a bit-field extract per value, a funnel shift where a field straddles two words).
+template <uint32_t BW>
+__device__ inline void bitpacked_fields16(const uint32_t (&x)[4], uint32_t (&w)[4]) {
+#pragma unroll
+    for (uint32_t q = 0; q < 4; q++) {
+        uint32_t o = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; i++) {
+            const uint32_t e = q * 4 + i, pos = 128 - (e + 1) * BW, k = pos >> 5, off = pos & 31;
+            uint32_t f;
+            if (off + BW <= 32) f = (x[k] >> off) & ((1u << BW) - 1);
+            else f = __builtin_amdgcn_alignbit(x[(k + 1) & 3], x[k], off) & ((1u << BW) - 1);
+            o |= f << (8 * i);
+        }
+        w[q] = o;
+    }
+}
+
+constexpr uint32_t BP_UNROLL = 4;
+
 __global__ __launch_bounds__(MT) void bitpacked_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
                                                        const uint32_t* __restrict__ items) {
     const uint32_t item = items[blockIdx.x];
@@ -90,34 +111,48 @@ __global__ __launch_bounds__(MT) void bitpacked_kernel(const DevPage* __restrict
         if (lead) finish(res, PQD_ERR_DST_TOO_SMALL, (int64_t)count, 0, 0, 0);
         return;
     }
-    const uint64_t tile = (uint64_t)MT * 16;
+    // A workgroup takes BP_UNROLL stretches of MT * 16 values at a time, a thread sixteen values of each: its loads
+    // are issued together (a workgroup of one load and one store per thread lives mostly on its own start-up).
+    const uint64_t tile = (uint64_t)MT * 16 * BP_UNROLL;
+    const bool dst_ok = ((uintptr_t)pg.dst & 3) == 0;
     for (uint64_t t = blockIdx.y; t * tile < count; t += gridDim.y) {
-        const uint64_t k = t * tile + (uint64_t)threadIdx.x * 16;
-        if (k >= count) continue;
         // Sixteen values start on a byte boundary (16 * bw bits) and take 2 * bw bytes.  Widths up to 8
         // with all sixteen bytes inside the page: one unaligned 16-byte load, read as a big-endian
         // 128-bit number whose fields are cut out from the top; 16-byte store.
-        const uint64_t byte0 = 2 * (k / 16) * bw;
-        if (bw <= 8 && k + 16 <= count && byte0 + 16 <= n && ((uintptr_t)(pg.dst + k) & 3) == 0) {
-            const u32x4_a1 raw = *(gptr<const u32x4_a1>)(src + byte0);
-            const uint64_t hi = ((uint64_t)__builtin_bswap32(raw.x) << 32) | __builtin_bswap32(raw.y);
-            const uint64_t lo = ((uint64_t)__builtin_bswap32(raw.z) << 32) | __builtin_bswap32(raw.w);
-            const uint32_t mask = (1u << bw) - 1;
-            uint32_t w[4] = {0, 0, 0, 0};
+        uint64_t k[BP_UNROLL];
+        bool fast[BP_UNROLL];
+        u32x4_a1 raw[BP_UNROLL];
 #pragma unroll
-            for (uint32_t e = 0; e < 16; e++) {
-                const uint32_t end = (e + 1) * bw; // bits from the top of the 128 to the end of field e
-                uint64_t f;
-                if (end <= 64) f = hi >> (64 - end);
-                else if (end - bw >= 64) f = lo >> (128 - end);
-                else f = (hi << (end - 64)) | (lo >> (128 - end));
-                w[e / 4] |= ((uint32_t)f & mask) << (8 * (e % 4));
+        for (uint32_t u = 0; u < BP_UNROLL; u++) {
+            k[u] = t * tile + (uint64_t)u * MT * 16 + (uint64_t)threadIdx.x * 16;
+            const uint64_t byte0 = 2 * (k[u] / 16) * bw;
+            fast[u] = bw <= 8 && k[u] + 16 <= count && byte0 + 16 <= n && dst_ok;
+            raw[u] = u32x4_a1{0, 0, 0, 0};
+            if (fast[u]) raw[u] = *(gptr<const u32x4_a1>)(src + byte0);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < BP_UNROLL; u++) {
+            if (k[u] >= count) continue;
+            if (fast[u]) {
+                // x[0] holds the last four bytes: field e lies 128 - (e + 1) * bw bits above the bottom
+                const uint32_t x[4] = {__builtin_bswap32(raw[u].w), __builtin_bswap32(raw[u].z), __builtin_bswap32(raw[u].y), __builtin_bswap32(raw[u].x)};
+                uint32_t w[4];
+                switch (bw) {
+                    case 1: bitpacked_fields16<1>(x, w); break;
+                    case 2: bitpacked_fields16<2>(x, w); break;
+                    case 3: bitpacked_fields16<3>(x, w); break;
+                    case 4: bitpacked_fields16<4>(x, w); break;
+                    case 5: bitpacked_fields16<5>(x, w); break;
+                    case 6: bitpacked_fields16<6>(x, w); break;
+                    case 7: bitpacked_fields16<7>(x, w); break;
+                    default: bitpacked_fields16<8>(x, w); break;
+                }
+                u32x4_a4 o;
+                o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+                *(gptr<u32x4_a4>)(dst + k[u]) = o;
+            } else {
+                for (uint32_t e = 0; e < 16 && k[u] + e < count; e++) dst[k[u] + e] = (uint8_t)bitpacked_value(src, n, k[u] + e, bw);
             }
-            u32x4_a4 o;
-            o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
-            *(gptr<u32x4_a4>)(dst + k) = o;
-        } else {
-            for (uint32_t e = 0; e < 16 && k + e < count; e++) dst[k + e] = (uint8_t)bitpacked_value(src, n, k + e, bw);
         }
     }
     if (lead) finish(res, PQD_OK, 0, count, count, n);
@@ -1152,7 +1187,7 @@ uint32_t tile_slots(uint64_t max_units, uint64_t per_tile) {
 void launch_bitpacked(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_values,
                       hipStream_t stream) {
     if (n_items == 0) return;
-    hipLaunchKernelGGL(bitpacked_kernel, dim3(n_items, tile_slots(max_values, MT * 16)), dim3(MT), 0, stream, pages, results, items);
+    hipLaunchKernelGGL(bitpacked_kernel, dim3(n_items, tile_slots(max_values, MT * 16 * BP_UNROLL)), dim3(MT), 0, stream, pages, results, items);
 }
 
 void launch_bss(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_bytes,
