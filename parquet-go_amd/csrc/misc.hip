@@ -225,6 +225,8 @@ __device__ inline void bss_tile(gptr<const uint8_t> src, gptr<uint8_t> dst, uint
     }
 }
 
+constexpr uint32_t BSS_UNROLL = 4;
+
 __global__ __launch_bounds__(MT) void bss_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
                                                  const uint32_t* __restrict__ items) {
     const uint32_t item = items[blockIdx.x];
@@ -236,15 +238,19 @@ __global__ __launch_bounds__(MT) void bss_kernel(const DevPage* __restrict__ pag
     if (!fixed_checks(pg, res, lead, width, &count)) return;
     gptr<const uint8_t> src = as_global(pg.src);
     gptr<uint8_t> dst = as_global(pg.dst);
-    const uint64_t tile = (uint64_t)MT * 4;
+    // a workgroup takes BSS_UNROLL stretches of MT * 4 values at a time (the compiler keeps their loads together)
+    const uint64_t tile = (uint64_t)MT * 4 * BSS_UNROLL;
     for (uint64_t t = blockIdx.y; t * tile < count; t += gridDim.y) {
-        const uint64_t k = t * tile + threadIdx.x * 4;
-        if (k >= count) continue;
-        if (width == 4) bss_tile<4>(src, dst, count, k);
-        else if (width == 8) bss_tile<8>(src, dst, count, k);
-        else {
-            for (uint64_t e = k; e < k + 4 && e < count; e++)
-                for (int32_t s = 0; s < width; s++) dst[e * (uint64_t)width + s] = src[(uint64_t)s * count + e];
+#pragma unroll
+        for (uint32_t u = 0; u < BSS_UNROLL; u++) {
+            const uint64_t k = t * tile + (uint64_t)u * MT * 4 + threadIdx.x * 4;
+            if (k >= count) continue;
+            if (width == 4) bss_tile<4>(src, dst, count, k);
+            else if (width == 8) bss_tile<8>(src, dst, count, k);
+            else {
+                for (uint64_t e = k; e < k + 4 && e < count; e++)
+                    for (int32_t s = 0; s < width; s++) dst[e * (uint64_t)width + s] = src[(uint64_t)s * count + e];
+            }
         }
     }
     if (lead) finish(res, PQD_OK, 0, count, pg.src_len, pg.src_len);
@@ -1193,7 +1199,7 @@ void launch_bitpacked(const DevPage* pages, DevResult* results, const uint32_t* 
 void launch_bss(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_bytes,
                 hipStream_t stream) {
     if (n_items == 0) return;
-    hipLaunchKernelGGL(bss_kernel, dim3(n_items, tile_slots(max_bytes / 4, MT * 4)), dim3(MT), 0, stream, pages, results, items);
+    hipLaunchKernelGGL(bss_kernel, dim3(n_items, tile_slots(max_bytes / 4, MT * 4 * BSS_UNROLL)), dim3(MT), 0, stream, pages, results, items);
 }
 
 void launch_plain_fixed(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_bytes,
