@@ -19,6 +19,12 @@ namespace {
 
 constexpr uint32_t LT = 256;          // threads per workgroup
 constexpr uint32_t STRETCH = 2048;    // levels per wavefront
+constexpr uint32_t COUNT_UNROLL = 4;  // stretches a wavefront of the counting kernel takes per turn
+constexpr uint32_t SCAN_TURN = 2048;  // entries a workgroup of the scan takes per turn
+constexpr uint32_t SCAN_GROUPS = 64;  // at most so many workgroups scan
+constexpr uint32_t COUNT_BITS = 12;   // a stretch's count (at most STRETCH) keeps the low bits of its entry after the scan
+constexpr uint64_t COUNT_MASK = (1u << COUNT_BITS) - 1;
+static_assert(STRETCH <= COUNT_MASK, "a count fits its bits");
 
 // Bytes of a dword equal to the bytes of `pattern` (the value in all four bytes).
 __device__ inline uint32_t equal_bytes(uint32_t x, uint32_t pattern) {
@@ -39,52 +45,94 @@ __global__ __launch_bounds__(LT) void levels_count_kernel(const uint8_t* __restr
     gptr<uint64_t> counts = as_global(counts_);
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t pattern = value * 0x01010101u;
-    for (uint64_t w = (uint64_t)blockIdx.x * (LT / 64) + wave; w < n_stretches; w += (uint64_t)gridDim.x * (LT / 64)) {
-        const uint64_t at = w * STRETCH;
-        uint32_t c = 0;
+    // COUNT_UNROLL stretches per wavefront and turn, their loads in flight together: a wavefront with two
+    // loads to wait for and a scan to do leaves the memory system idle most of its life
+    for (uint64_t w0 = ((uint64_t)blockIdx.x * (LT / 64) + wave) * COUNT_UNROLL; w0 < n_stretches;
+         w0 += (uint64_t)gridDim.x * (LT / 64) * COUNT_UNROLL) {
+        constexpr uint32_t PER = STRETCH / (64 * 16);
+        u32x4_a4 v[COUNT_UNROLL * PER];
+        uint32_t whole = 0; // bit j * PER + u: lane's 16 bytes of that load are all in range and dword aligned
 #pragma unroll
-        for (uint32_t u = 0; u < STRETCH / (64 * 16); u++) {
-            const uint64_t b = at + (uint64_t)(u * 64 + lane) * 16;
-            if (b + 16 <= n && ((uintptr_t)(levels_ + b) & 3) == 0) {
-                const u32x4_a4 v = *(gptr<const u32x4_a4>)(levels + b);
-                c += equal_bytes(v.x, pattern) + equal_bytes(v.y, pattern) + equal_bytes(v.z, pattern) + equal_bytes(v.w, pattern);
-            } else {
-                for (uint32_t e = 0; e < 16 && b + e < n; e++) c += levels[b + e] == value ? 1u : 0u;
+        for (uint32_t j = 0; j < COUNT_UNROLL; j++) {
+#pragma unroll
+            for (uint32_t u = 0; u < PER; u++) {
+                const uint64_t b = (w0 + j) * STRETCH + (uint64_t)(u * 64 + lane) * 16;
+                v[j * PER + u] = u32x4_a4{0, 0, 0, 0};
+                if (b + 16 <= n && ((uintptr_t)(levels_ + b) & 3) == 0) {
+                    v[j * PER + u] = *(gptr<const u32x4_a4>)(levels + b);
+                    whole |= 1u << (j * PER + u);
+                }
             }
         }
-        const uint32_t total = lane_u32(wave_inclusive_scan<uint32_t>(c), 63);
-        if (lane == 0) counts[w] = total;
+#pragma unroll
+        for (uint32_t j = 0; j < COUNT_UNROLL; j++) {
+            if (w0 + j >= n_stretches) break;
+            uint32_t c = 0;
+#pragma unroll
+            for (uint32_t u = 0; u < PER; u++) {
+                const uint64_t b = (w0 + j) * STRETCH + (uint64_t)(u * 64 + lane) * 16;
+                if (whole >> (j * PER + u) & 1) {
+                    const u32x4_a4 x = v[j * PER + u];
+                    c += equal_bytes(x.x, pattern) + equal_bytes(x.y, pattern) + equal_bytes(x.z, pattern) + equal_bytes(x.w, pattern);
+                } else {
+                    for (uint32_t e = 0; e < 16 && b + e < n; e++) c += levels[b + e] == value ? 1u : 0u;
+                }
+            }
+            const uint32_t total = lane_u32(wave_inclusive_scan<uint32_t>(c), 63);
+            if (lane == 0) counts[w0 + j] = total;
+        }
     }
 }
 
-// One workgroup: counts become exclusive sums in place, the total goes to counts[n_stretches]
-// and, when asked for, to `total_out`.
-__global__ __launch_bounds__(1024) void levels_scan_kernel(uint64_t* __restrict__ counts_, uint64_t n_stretches,
+// The counts become (start << COUNT_BITS | count) in place, start being the sum of the counts before; the total
+// goes to counts[n_stretches], as it is, and, when asked for, to `total_out`.  Workgroup g owns `chunk` entries
+// (a multiple of SCAN_TURN) and first adds up the counts of every entry before its own: whether another
+// workgroup has already rewritten an entry or not, its low COUNT_BITS bits are the count.  One workgroup for
+// the whole array spends its time waiting on one compute unit's path to memory.
+__global__ __launch_bounds__(1024) void levels_scan_kernel(uint64_t* __restrict__ counts_, uint64_t n_stretches, uint64_t chunk,
                                                            uint64_t* __restrict__ total_out) {
     __shared__ uint64_t wsum[16];
     gptr<uint64_t> counts = as_global(counts_);
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint64_t carry = 0;
-    for (uint64_t base = 0; base < n_stretches; base += 1024 * 4) {
-        const uint64_t k = base + (uint64_t)tid * 4;
-        uint64_t v[4];
-        for (uint32_t e = 0; e < 4; e++) v[e] = k + e < n_stretches ? counts[k + e] : 0;
-        const uint64_t mine = v[0] + v[1] + v[2] + v[3];
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk;
+    const uint64_t hi = lo + chunk < n_stretches ? lo + chunk : n_stretches;
+    uint64_t before = 0;
+#pragma unroll 8
+    for (uint64_t j = (uint64_t)tid * 2; j < lo; j += 2048) { // lo is a multiple of 2048: pairs never straddle it
+        const u32x4_a4 p = *(gptr<const u32x4_a4>)(counts + j);
+        before += (p.x & COUNT_MASK) + (p.z & COUNT_MASK);
+    }
+    {
+        const uint64_t x = wave_inclusive_scan<uint64_t>(before);
+        if (lane == 63) wsum[wave] = x;
+        __syncthreads();
+        before = 0;
+        for (uint32_t w = 0; w < 16; w++) before += wsum[w];
+        __syncthreads();
+    }
+    uint64_t carry = before;
+    for (uint64_t base = lo; base < hi; base += SCAN_TURN) {
+        constexpr uint32_t PER = SCAN_TURN / 1024;
+        const uint64_t k = base + (uint64_t)tid * PER;
+        uint64_t v[PER], mine = 0;
+        for (uint32_t e = 0; e < PER; e++) {
+            v[e] = k + e < hi ? counts[k + e] & COUNT_MASK : 0;
+            mine += v[e];
+        }
         const uint64_t x = wave_inclusive_scan<uint64_t>(mine);
         if (lane == 63) wsum[wave] = x;
         __syncthreads();
-        uint64_t before = carry, all = 0;
+        uint64_t o = carry + x - mine, all = 0;
         for (uint32_t w = 0; w < 16; w++) {
-            if (w < wave) before += wsum[w];
+            if (w < wave) o += wsum[w];
             all += wsum[w];
         }
-        uint64_t o = before + x - mine;
-        for (uint32_t e = 0; e < 4; e++)
-            if (k + e < n_stretches) { counts[k + e] = o; o += v[e]; }
+        for (uint32_t e = 0; e < PER; e++)
+            if (k + e < hi) { counts[k + e] = o << COUNT_BITS | v[e]; o += v[e]; }
         carry += all;
         __syncthreads();
     }
-    if (tid == 0) {
+    if (tid == 0 && hi == n_stretches) {
         counts[n_stretches] = carry;
         if (total_out != nullptr) *as_global(total_out) = carry;
     }
@@ -117,7 +165,7 @@ __global__ __launch_bounds__(LT) void optional_expand_kernel(const uint8_t* __re
         if (OFFSETS) dst[n_slots] = values[present < n_values ? present : n_values];
     }
     for (uint64_t w = (uint64_t)blockIdx.x * (LT / 64) + wave; w < n_stretches; w += (uint64_t)gridDim.x * (LT / 64)) {
-        uint64_t base = starts[w];
+        uint64_t base = starts[w] >> COUNT_BITS;
         const uint64_t at = w * STRETCH;
         constexpr uint32_t STEPS = STRETCH / 128;
         uint32_t lv[STEPS];
@@ -180,7 +228,7 @@ __global__ __launch_bounds__(LT) void optional_expand_bytes_kernel(const uint8_t
         info[1] = present > n_values ? PQD_ERR_UNEXPECTED_EOF : PQD_OK;
     }
     for (uint64_t w = (uint64_t)blockIdx.x * (LT / 64) + wave; w < n_stretches; w += (uint64_t)gridDim.x * (LT / 64)) {
-        uint64_t base = starts[w];
+        uint64_t base = starts[w] >> COUNT_BITS;
         for (uint32_t u = 0; u < STRETCH / 64; u++) {
             const uint64_t s0 = w * STRETCH + u * 64 + lane;
             const bool in = s0 < n_slots;
@@ -212,15 +260,50 @@ __global__ __launch_bounds__(LT) void row_starts_kernel(const uint8_t* __restric
         info[1] = n_rows + 1 > row_cap ? PQD_ERR_DST_TOO_SMALL : PQD_OK;
         if (n_rows < row_cap) rows[n_rows] = n; // the end of the last row
     }
+    __shared__ uint16_t stage[LT / 64][64 * 16];
     for (uint64_t w = (uint64_t)blockIdx.x * (LT / 64) + wave; w < n_stretches; w += (uint64_t)gridDim.x * (LT / 64)) {
-        uint64_t base = starts[w];
-        for (uint32_t u = 0; u < STRETCH / 64; u++) {
-            const uint64_t s0 = w * STRETCH + u * 64 + lane;
-            const bool z = s0 < n && rep[s0] == 0;
-            const unsigned long long b = __ballot(z);
-            const uint64_t r = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
-            if (z && r < row_cap) rows[r] = s0;
-            base += (uint64_t)__popcll(b);
+        uint64_t base = starts[w] >> COUNT_BITS;
+        // sixteen levels per lane and step: one 16-byte load, the zero bytes as a 16-bit mask (four bits per
+        // dword by a multiplication), a wave scan of their counts, then every lane writes the places of its own
+        uint32_t m[STRETCH / (64 * 16)];
+#pragma unroll
+        for (uint32_t u = 0; u < STRETCH / (64 * 16); u++) {
+            const uint64_t s0 = w * STRETCH + (uint64_t)(u * 64 + lane) * 16;
+            uint32_t mask = 0;
+            if (s0 + 16 <= n && ((uintptr_t)(rep_ + s0) & 3) == 0) {
+                const u32x4_a4 v = *(gptr<const u32x4_a4>)(rep + s0);
+                const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (uint32_t k = 0; k < 4; k++) {
+                    const uint32_t t = d[k];
+                    const uint32_t y = ~(((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t | 0x7f7f7f7fu); // 0x80 in every zero byte
+                    mask |= ((((y >> 7) * 0x00204081u) >> 21) & 0xfu) << (4 * k);
+                }
+            } else {
+                for (uint32_t e = 0; e < 16 && s0 + e < n; e++) mask |= rep[s0 + e] == 0 ? 1u << e : 0u;
+            }
+            m[u] = mask;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < STRETCH / (64 * 16); u++) {
+            const uint64_t s0 = w * STRETCH + (uint64_t)(u * 64 + lane) * 16;
+            const uint32_t cnt = (uint32_t)__popc(m[u]);
+            const uint32_t incl = wave_inclusive_scan<uint32_t>(cnt);
+            const uint32_t total = lane_u32(incl, 63);
+            // the places within the step go through the wavefront's own corner of LDS in their order, and
+            // come out 64 neighbours at a time: whole cache lines instead of a few entries per lane
+            uint32_t r = incl - cnt;
+            for (uint32_t left = m[u]; left; left &= left - 1, r++)
+                stage[wave][r] = (uint16_t)(lane * 16 + (uint32_t)__builtin_ctz(left));
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const uint64_t step0 = s0 - (uint64_t)lane * 16;
+            for (uint32_t t = lane; t < total; t += 64)
+                if (base + t < row_cap) rows[base + t] = step0 + stage[wave][t];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            base += total;
         }
     }
 }
@@ -240,13 +323,22 @@ uint32_t groups_for(uint64_t n_stretches) {
     return (uint32_t)(g < 1 ? 1 : (g > 65536 ? 65536 : g));
 }
 
+uint32_t count_groups_for(uint64_t n_stretches) { return groups_for((n_stretches + COUNT_UNROLL - 1) / COUNT_UNROLL); }
+
 bool count_and_scan(const uint8_t* levels, uint64_t n, uint8_t value, void* workspace, uint64_t workspace_bytes, uint64_t* total,
                     hipStream_t s) {
     const uint64_t ns = stretches_of(n);
     if (workspace == nullptr || workspace_bytes < (ns + 1) * sizeof(uint64_t) || ((uintptr_t)workspace & 7) != 0) return false;
     uint64_t* counts = static_cast<uint64_t*>(workspace);
-    if (ns > 0) hipLaunchKernelGGL(levels_count_kernel, dim3(groups_for(ns)), dim3(LT), 0, s, levels, n, (uint32_t)value, ns, counts);
-    hipLaunchKernelGGL(levels_scan_kernel, dim3(1), dim3(1024), 0, s, counts, ns, total);
+    if (ns > 0) hipLaunchKernelGGL(levels_count_kernel, dim3(count_groups_for(ns)), dim3(LT), 0, s, levels, n, (uint32_t)value, ns, counts);
+    // every workgroup of the scan owns a whole number of turns; an empty array still gets its total written
+    uint64_t groups = (ns + SCAN_TURN - 1) / SCAN_TURN;
+    if (groups < 1) groups = 1;
+    if (groups > SCAN_GROUPS) groups = SCAN_GROUPS;
+    const uint64_t chunk = ((ns + groups - 1) / groups + SCAN_TURN - 1) / SCAN_TURN * SCAN_TURN;
+    groups = chunk ? (ns + chunk - 1) / chunk : 1;
+    if (groups < 1) groups = 1;
+    hipLaunchKernelGGL(levels_scan_kernel, dim3((uint32_t)groups), dim3(1024), 0, s, counts, ns, chunk ? chunk : SCAN_TURN, total);
     return true;
 }
 

@@ -112,3 +112,38 @@ def test_row_starts():
     r = np.zeros(1000, np.uint8)
     rows, n_rows, status = P.levels.repeated_row_starts(ctx(), r, row_cap=10)
     assert n_rows == 1000 and status == P.STATUS.DST_TOO_SMALL and rows.tolist() == list(range(10))
+
+
+def test_row_starts_misaligned_and_short_capacity():
+    P = pkg()
+    rng = np.random.default_rng(36)
+    for n in (15, 16, 17, 1023, 1025, 2049, 70001):
+        r = np.where(rng.random(n) < 0.3, 0, 1).astype(np.uint8)
+        want = L.repeated_row_starts(r)
+        for mis in (1, 2, 3, 7):
+            rows, n_rows, status = P.levels.repeated_row_starts(ctx(), P.to_device(r, misalign=mis))
+            assert status == 0 and np.array_equal(rows[: n_rows + 1], want), (n, mis)
+        cap = max(1, (want.size - 1) // 2)
+        rows, n_rows, status = P.levels.repeated_row_starts(ctx(), r, row_cap=cap)
+        assert n_rows == want.size - 1
+        assert np.array_equal(rows[:cap], want[:cap]), n
+
+
+@pytest.mark.parametrize("n", [(1 << 22) + 1, 9_000_001, (1 << 25) + 4099])
+def test_long_columns(n):
+    # beyond 2048 stretches of 2048 levels several workgroups share the running sums of the counts
+    P = pkg()
+    rng = np.random.default_rng(37)
+    d = _levels(rng, n, 1, 0.3, 0)
+    d[n // 3: n // 3 + 200000] = 0  # stretches without a value
+    d[n // 2: n // 2 + 200000] = 1  # and full ones
+    present = int((d == 1).sum())
+    assert P.levels.count_levels_equal(ctx(), d, 1) == present
+    vals = rng.integers(1, 2**31, size=present, dtype=np.int32)
+    want, validity, cnt, eof = L.optional_read_values(d, 1, vals, 4)
+    out = P.levels.optional_expand(ctx(), d, 1, vals, present, 4)
+    assert out.status == 0 and out.present == cnt
+    assert out.values.tobytes() == want.tobytes() and out.validity.tobytes() == validity.tobytes()
+    want = L.repeated_row_starts(d)
+    rows, n_rows, status = P.levels.repeated_row_starts(ctx(), d)
+    assert status == 0 and n_rows == want.size - 1 and np.array_equal(rows[: n_rows + 1], want)
