@@ -397,6 +397,28 @@ __global__ __launch_bounds__(WT) void plain_byte_array_kernel(const DevPage* __r
                     p = lane_u32(c, l) + 4 + guess;
                     cnt += valid;
                 }
+                if (valid > 0 && valid <= 2 && stop_what == 0 && cnt < PBATCH) {
+                    // Lengths that differ from record to record: a round costs some sixty instructions and
+                    // yields one record.  The wavefront then follows the chain itself, one uniform LDS read per
+                    // record, for the rest of the batch; anything but a whole, staged, fitting record ends
+                    // the chase and is left to the next round above, which knows what to call it.
+                    uint32_t pp = (uint32_t)__builtin_amdgcn_readfirstlane((int)p);
+                    uint32_t c = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt);
+                    uint32_t my_pos = 0, my_len = 0, last = guess;
+                    while (c < PBATCH && (uint64_t)pp + 4 <= avail) {
+                        const uint32_t l = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_u32(stage32, pp));
+                        if (l > left - pp - 4 || l > avail - pp - 4) break;
+                        if (lane == c) { my_pos = pp + 4; my_len = l; }
+                        pp += 4 + l;
+                        last = l;
+                        c++;
+                    }
+                    if (lane >= cnt && lane < c) { v_pos[lane] = my_pos; v_len[lane] = my_len; }
+                    guess = last;
+                    p = pp;
+                    cnt = c;
+                    continue;
+                }
                 if (valid == 0 || (valid <= lead && lead < 64 && stop_what != 0)) {
                     // the record after the valid ones cannot be taken this round
                     const uint32_t at = valid == 0 ? 0 : lead; // lane holding it (valid == lead here)

@@ -58,10 +58,44 @@ struct PbShared {
     uint8_t err[PT];
     uint8_t reach[PT];
     uint32_t wave_sum[PT / 64];
+    uint32_t part[4][PT / 64];      // per wavefront: least guess, last lane with one, records, last record
     uint32_t all_ok, first_guess, last_lane, term_lane, term_type, count, last_start;
 };
 
 __device__ inline void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// Wavefront-wide least / greatest / sum, the same in every lane.  (An LDS atomic of all lanes on one address is
+// turned by the compiler into a loop over the lanes, half a dozen scalar instructions each: four of them per tile
+// and the compute unit's one scalar unit is what the kernel waits for.)
+__device__ inline uint32_t wave_least(uint32_t v) {
+    for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, d); v = o < v ? o : v; }
+    return v;
+}
+__device__ inline uint32_t wave_greatest(uint32_t v) {
+    for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, d); v = o > v ? o : v; }
+    return v;
+}
+__device__ inline uint32_t wave_total(uint32_t v) {
+    for (int d = 32; d > 0; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
+    return v;
+}
+
+// sh.part[k] of the four wavefronts, combined; k as in the declaration.
+__device__ inline uint32_t part_least(const PbShared& sh, uint32_t k) {
+    uint32_t v = sh.part[k][0];
+    for (uint32_t w = 1; w < PT / 64; w++) v = std::min(v, sh.part[k][w]);
+    return v;
+}
+__device__ inline uint32_t part_greatest(const PbShared& sh, uint32_t k) {
+    uint32_t v = sh.part[k][0];
+    for (uint32_t w = 1; w < PT / 64; w++) v = std::max(v, sh.part[k][w]);
+    return v;
+}
+__device__ inline uint32_t part_total(const PbShared& sh, uint32_t k) {
+    uint32_t v = 0;
+    for (uint32_t w = 0; w < PT / 64; w++) v += sh.part[k][w];
+    return v;
+}
 
 // The page as a tile sees it; positions inside a tile are relative to its first byte.
 struct Tile {
@@ -85,11 +119,20 @@ __device__ inline Tile make_tile(const DevPage& pg, uint64_t tile) {
 }
 
 __device__ inline void stage_tile(PbShared& sh, const Tile& t) {
-    // 16 bytes per lane and step; the page may start at any address
+    // 16 bytes per lane and step, the steps' loads in flight together (a loop of load, wait, store keeps
+    // 4 KB per workgroup under way and the memory idle); the page may start at any address
+    constexpr uint32_t STEPS = (PTILE + PLOOK + 16 * PT - 1) / (16 * PT);
     const uint32_t body = t.staged / 16;
-    for (uint32_t c = threadIdx.x; c < body; c += PT) {
-        const u32x4_a1 w = *(gptr<const u32x4_a1>)(t.src + t.base + (uint64_t)c * 16);
-        *reinterpret_cast<u32x4*>(&sh.stage[c * 4]) = w;
+    u32x4_a1 w[STEPS];
+#pragma unroll
+    for (uint32_t u = 0; u < STEPS; u++) {
+        const uint32_t c = threadIdx.x + u * PT;
+        if (c < body) w[u] = *(gptr<const u32x4_a1>)(t.src + t.base + (uint64_t)c * 16);
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < STEPS; u++) {
+        const uint32_t c = threadIdx.x + u * PT;
+        if (c < body) *reinterpret_cast<u32x4*>(&sh.stage[c * 4]) = w[u];
     }
     uint8_t* bytes = reinterpret_cast<uint8_t*>(sh.stage);
     for (uint32_t k = body * 16 + threadIdx.x; k < t.staged; k += PT) bytes[k] = t.src[t.base + k];
@@ -146,9 +189,16 @@ __device__ inline void walk_lane(PbShared& sh, const Tile& t, uint32_t lane, uin
 __device__ inline void zero_bytes(const PbShared& sh, uint32_t lane, unsigned long long* lo, uint32_t* hi) {
     unsigned long long z = 0;
     uint32_t top = 0;
+    uint32_t d[17]; // four 16-byte reads and one more dword: a quarter of the bank conflicts of seventeen dword reads
+#pragma unroll
+    for (uint32_t i = 0; i < 4; i++) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(&sh.stage[lane * (PSUB / 4) + 4 * i]);
+        d[4 * i] = v.x; d[4 * i + 1] = v.y; d[4 * i + 2] = v.z; d[4 * i + 3] = v.w;
+    }
+    d[16] = sh.stage[lane * (PSUB / 4) + 16];
 #pragma unroll
     for (uint32_t i = 0; i < 17; i++) {
-        const uint32_t w = sh.stage[lane * (PSUB / 4) + i];
+        const uint32_t w = d[i];
         const uint32_t y = ~(((w & 0x7f7f7f7fu) + 0x7f7f7f7fu) | w | 0x7f7f7f7fu); // 0x80 in every zero byte
         const uint32_t nib = (((y >> 7) * 0x00204081u) >> 21) & 0xfu;
         if (i < 16) z |= (unsigned long long)nib << (4 * i);
@@ -207,11 +257,15 @@ __device__ inline void resolve_tile(PbShared& sh, const Tile& t, uint32_t entry)
     sh.starts[lane] = 0; sh.err[lane] = 0; sh.exit_[lane] = 0;
     if (g != P_NONE) {
         walk_lane(sh, t, lane, g);
-        atomicMin(&sh.first_guess, g);
-        atomicMax(&sh.last_lane, lane);
         const uint32_t x = sh.exit_[lane];
         if (!sh.err[lane] && x < t.bytes) atomicOr(&sh.exits[x >> 5], 1u << (x & 31));
     }
+    {
+        const uint32_t least = wave_least(g), last = wave_greatest(g != P_NONE ? lane : 0u);
+        if ((lane & 63) == 0) { sh.part[0][lane >> 6] = least; sh.part[1][lane >> 6] = last; }
+    }
+    lds_sync();
+    if (lane == 0) { sh.first_guess = part_least(sh, 0); sh.last_lane = part_greatest(sh, 1); }
     lds_sync();
     const uint32_t start = entry != P_NONE ? entry : sh.first_guess;
     if (start == P_NONE) { // no record starts in this tile as far as anyone can tell
@@ -276,11 +330,99 @@ __device__ inline void resolve_tile(PbShared& sh, const Tile& t, uint32_t entry)
     }
     // ---- the records of the chain: how many, and the last ----
     const unsigned long long mine = sh.reach[lane] ? sh.starts[lane] : 0;
-    if (mine) {
-        atomicAdd(&sh.count, (uint32_t)__builtin_popcountll(mine));
-        atomicMax(&sh.last_start, lane * PSUB + 63 - (uint32_t)__builtin_clzll(mine));
+    {
+        const uint32_t records = wave_total((uint32_t)__builtin_popcountll(mine));
+        const uint32_t last = wave_greatest(mine ? lane * PSUB + 63 - (uint32_t)__builtin_clzll(mine) : 0u);
+        if ((lane & 63) == 0) { sh.part[2][lane >> 6] = records; sh.part[3][lane >> 6] = last; }
     }
     lds_sync();
+    if (lane == 0) { sh.count = part_total(sh, 2); sh.last_start = part_greatest(sh, 3); }
+    lds_sync();
+}
+
+// The same result as resolve_tile for the pages most byte-array columns make -- values shorter than 256 bytes
+// with few zero bytes in them (text) -- at a fraction of the work; false when the tile is not like that, and
+// resolve_tile has to be asked.  A position whose next three bytes are zero is taken for a record start (the last
+// of a row of such positions: an empty value makes a row of two).  Every one of them sends a mark to where its
+// record ends.  When the marked positions are the candidates themselves, all but the first, the candidates are a
+// chain: each has one successor, so N candidates send at most N - 1 marks into the tile (the last one's leaves
+// it); N - 1 distinct marked positions then mean every candidate but the first is the end of exactly one other,
+// and following the ends from the first reaches them all.
+__device__ inline bool resolve_tile_text(PbShared& sh, const Tile& t, uint32_t entry) {
+    if (!t.narrow) return false;
+    const uint32_t lane = threadIdx.x, lo = lane * PSUB;
+    if (lane == 0) { sh.first_guess = P_NONE; sh.all_ok = 1; sh.last_lane = 0; sh.count = 0; sh.last_start = 0; sh.term_type = T_NONE; sh.term_lane = 0; }
+    sh.exits[2 * lane] = 0;
+    sh.exits[2 * lane + 1] = 0;
+    lds_sync();
+    unsigned long long mask = 0;
+    uint32_t exit_at = 0;
+    bool ok = true;
+    if (lo < t.bytes) {
+        unsigned long long z;
+        uint32_t top; // zero bytes at 64 .. 67 of the sub-chunk
+        zero_bytes(sh, lane, &z, &top);
+        const unsigned long long cand = ((z >> 1) | (unsigned long long)(top & 1u) << 63) & ((z >> 2) | (unsigned long long)(top & 3u) << 62) &
+                                        ((z >> 3) | (unsigned long long)(top & 7u) << 61);
+        const unsigned long long cand_next = (cand >> 1) | ((top & 0xeu) == 0xeu ? 1ull << 63 : 0ull);
+        mask = cand & ~cand_next;
+        // positions of the tile whose length field lies inside the page, from the entry on
+        const uint32_t lim = std::min(t.bytes, t.rem >= 4 ? t.rem - 3 : 0u);
+        if (lim <= lo) mask = 0;
+        else if (lim - lo < PSUB) mask &= (1ull << (lim - lo)) - 1;
+        if (entry != P_NONE) {
+            if (lo + PSUB <= entry) mask = 0;
+            else if (lo <= entry) {
+                mask &= ~((1ull << (entry - lo)) - 1);
+                if (!(mask >> (entry - lo) & 1)) ok = false; // the chain enters at a position that is no candidate
+            }
+        }
+        for (unsigned long long m = mask; m; m &= m - 1) {
+            const uint32_t q = lo + (uint32_t)__builtin_ctzll(m);
+            const uint32_t len = length_at(sh, q);
+            if (len > t.rem - q - 4) { ok = false; break; }
+            exit_at = q + 4 + len;
+            if (exit_at < t.bytes) atomicOr(&sh.exits[exit_at >> 5], 1u << (exit_at & 31));
+        }
+    }
+    const uint32_t g = mask ? lo + (uint32_t)__builtin_ctzll(mask) : P_NONE;
+    sh.starts[lane] = mask;
+    sh.exit_[lane] = exit_at;
+    sh.err[lane] = 0;
+    sh.guess[lane] = g;
+    {
+        const uint32_t least = wave_least(g), last = wave_greatest(mask ? lane : 0u);
+        const uint32_t records = wave_total((uint32_t)__builtin_popcountll(mask));
+        const uint32_t last_start = wave_greatest(mask ? lo + 63 - (uint32_t)__builtin_clzll(mask) : 0u);
+        if ((lane & 63) == 0) {
+            sh.part[0][lane >> 6] = least; sh.part[1][lane >> 6] = last;
+            sh.part[2][lane >> 6] = records; sh.part[3][lane >> 6] = last_start;
+        }
+    }
+    lds_sync();
+    const uint32_t first_guess = part_least(sh, 0);
+    const uint32_t start = entry != P_NONE ? entry : first_guess;
+    if (start == P_NONE) return false; // nothing here looks like text
+    {
+        const unsigned long long marked = (unsigned long long)sh.exits[2 * lane] | (unsigned long long)sh.exits[2 * lane + 1] << 32;
+        unsigned long long want = mask;
+        if (start >= lo && start < lo + PSUB) want &= ~(1ull << (start - lo));
+        if (marked != want) ok = false;
+    }
+    if (!ok) sh.all_ok = 0;
+    lds_sync();
+    if (!sh.all_ok) return false;
+    sh.reach[lane] = mask ? 1 : 0;
+    if (lane == 0) {
+        sh.first_guess = first_guess;
+        sh.last_lane = part_greatest(sh, 1);
+        sh.term_lane = sh.last_lane;
+        sh.term_type = T_END;
+        sh.count = part_total(sh, 2);
+        sh.last_start = part_greatest(sh, 3);
+    }
+    lds_sync();
+    return true;
 }
 
 // Pass one: every tile from its own guess.
@@ -295,7 +437,7 @@ __global__ __launch_bounds__(PT) void plain_bytes_guess_kernel(const DevPage* __
         lds_sync(); // the tile before is done with the shared memory
         stage_tile(sh, t);
         lds_sync();
-        resolve_tile(sh, t, tile == 0 ? 0u : P_NONE);
+        if (!resolve_tile_text(sh, t, tile == 0 ? 0u : P_NONE)) resolve_tile(sh, t, tile == 0 ? 0u : P_NONE);
         if (threadIdx.x == 0) {
             gptr<uint32_t> w = words + tile * TW_WORDS;
             const uint32_t type = sh.term_type;
@@ -434,7 +576,9 @@ __global__ __launch_bounds__(PT) void plain_bytes_copy_kernel(const DevPage* __r
         lds_sync();
         stage_tile(sh, t);
         lds_sync();
-        if (entry != P_NONE) resolve_tile(sh, t, entry - (uint32_t)t.base);
+        if (entry != P_NONE) {
+            if (!resolve_tile_text(sh, t, entry - (uint32_t)t.base)) resolve_tile(sh, t, entry - (uint32_t)t.base);
+        }
         else { sh.starts[lane] = 0; sh.reach[lane] = 0; lds_sync(); }
         // ---- records in front of every sub-chunk: a prefix sum over the lanes ----
         unsigned long long starts = sh.starts[lane];

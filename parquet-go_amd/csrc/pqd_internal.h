@@ -195,6 +195,21 @@ __device__ inline U wave_inclusive_scan(U x) {
     return x;
 }
 
+// Greatest / least value over the 64 lanes, the same in every lane.  Where all lanes would otherwise send an
+// atomic to one LDS or global address: the compiler turns that into a loop over the active lanes, half a dozen
+// scalar instructions for each, on the one scalar unit the compute unit's wavefronts share.
+__device__ inline uint32_t wave_greatest_u32(uint32_t x) {
+    uint32_t o;
+    o = dpp0<0x111, 0xf>(x); x = o > x ? o : x;
+    o = dpp0<0x112, 0xf>(x); x = o > x ? o : x;
+    o = dpp0<0x114, 0xf>(x); x = o > x ? o : x;
+    o = dpp0<0x118, 0xf>(x); x = o > x ? o : x;
+    o = dpp0<0x142, 0xa>(x); x = o > x ? o : x;
+    o = dpp0<0x143, 0xc>(x); x = o > x ? o : x;
+    return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ inline uint32_t wave_least_u32(uint32_t x) { return ~wave_greatest_u32(~x); }
+
 // Value of a register in the lane a wave-uniform index names (v_readlane: no LDS round trip).
 __device__ inline uint32_t lane_u32(uint32_t v, uint32_t lane) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)lane); }
 __device__ inline uint64_t lane_u64(uint64_t v, uint32_t lane) {

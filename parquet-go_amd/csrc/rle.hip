@@ -948,15 +948,22 @@ __device__ inline void expand_tile(EShared& sh, const DevPage& pg, DevResult* re
         }
         const u32x4 last = tab[in_tile - 1];
         bool in_lds = (uint64_t)last.x + (last.w >> 1) >= t0 + n_stream; // else the tile goes on past the staged entries
-        for (uint32_t k = tid; k < in_tile; k += ET) {
-            const u32x4 e = tab[k];
-            if (e.w & 1) {
-                const uint64_t rb = e.x, re = rb + (e.w >> 1);
-                const uint64_t s0 = rb > t0 ? rb : t0, s1 = re < t0 + n_stream ? re : t0 + n_stream;
-                if (s1 > s0) {
-                    atomicMin(&sh.span_lo, e.y + (uint32_t)(((s0 - rb) * bw) >> 3));
-                    atomicMax(&sh.span_hi, e.y + (uint32_t)(((s1 - rb) * bw + 7) >> 3));
+        {
+            uint32_t my_lo = 0xffffffffu, my_hi = 0;
+            for (uint32_t k = tid; k < in_tile; k += ET) {
+                const u32x4 e = tab[k];
+                if (e.w & 1) {
+                    const uint64_t rb = e.x, re = rb + (e.w >> 1);
+                    const uint64_t s0 = rb > t0 ? rb : t0, s1 = re < t0 + n_stream ? re : t0 + n_stream;
+                    if (s1 > s0) {
+                        my_lo = min(my_lo, e.y + (uint32_t)(((s0 - rb) * bw) >> 3));
+                        my_hi = max(my_hi, e.y + (uint32_t)(((s1 - rb) * bw + 7) >> 3));
+                    }
                 }
+            }
+            if ((tid & ~63u) < in_tile) { // one atomic per wavefront that saw an entry
+                const uint32_t w_lo = wave_least_u32(my_lo), w_hi = wave_greatest_u32(my_hi);
+                if ((tid & 63) == 0 && w_lo != 0xffffffffu) { atomicMin(&sh.span_lo, w_lo); atomicMax(&sh.span_hi, w_hi); }
             }
         }
         __syncthreads();
@@ -1131,15 +1138,22 @@ __device__ __forceinline__ bool expand_group_bytes(EShared& sh, const DevPage& p
         const u32x4 last = tab[nr - 1];
         if ((uint64_t)last.x + (last.w >> 1) < G0 + GS) return false; // the group runs past the staged entries
     }
-    for (uint32_t k = tid; k < nr; k += ET) {
-        const u32x4 r = tab[k];
-        if (r.w & 1) {
-            const uint64_t rb = r.x, re = rb + (r.w >> 1);
-            const uint64_t s0 = rb > G0 ? rb : G0, s1 = re < G0 + GS ? re : G0 + GS;
-            if (s1 > s0) {
-                atomicMin(&sh.span_lo, r.y + (uint32_t)(((s0 - rb) * bw) >> 3));
-                atomicMax(&sh.span_hi, r.y + (uint32_t)(((s1 - rb) * bw + 7) >> 3));
+    {
+        uint32_t my_lo = 0xffffffffu, my_hi = 0;
+        for (uint32_t k = tid; k < nr; k += ET) {
+            const u32x4 r = tab[k];
+            if (r.w & 1) {
+                const uint64_t rb = r.x, re = rb + (r.w >> 1);
+                const uint64_t s0 = rb > G0 ? rb : G0, s1 = re < G0 + GS ? re : G0 + GS;
+                if (s1 > s0) {
+                    my_lo = min(my_lo, r.y + (uint32_t)(((s0 - rb) * bw) >> 3));
+                    my_hi = max(my_hi, r.y + (uint32_t)(((s1 - rb) * bw + 7) >> 3));
+                }
             }
+        }
+        if ((tid & ~63u) < nr) { // one atomic per wavefront that saw an entry
+            const uint32_t w_lo = wave_least_u32(my_lo), w_hi = wave_greatest_u32(my_hi);
+            if ((tid & 63) == 0 && w_lo != 0xffffffffu) { atomicMin(&sh.span_lo, w_lo); atomicMax(&sh.span_hi, w_hi); }
         }
     }
     __syncthreads();
