@@ -45,6 +45,9 @@ constexpr uint32_t T_END = 256, T_ERR = 257, T_BROKEN = 258, T_NONE = 259;
 
 typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
 typedef uint32_t u32x3_a1 __attribute__((ext_vector_type(3), aligned(1)));
+typedef unsigned long long u64_a1 __attribute__((aligned(1)));
+typedef uint16_t u16_a1 __attribute__((aligned(1)));
+typedef uint32_t u32_a1 __attribute__((aligned(1)));
 
 struct PbShared {
     alignas(16) uint32_t stage[(PTILE + PLOOK) / 4 + 16];
@@ -411,7 +414,9 @@ __device__ inline bool resolve_tile_text(PbShared& sh, const Tile& t, uint32_t e
     }
     if (!ok) sh.all_ok = 0;
     lds_sync();
-    if (!sh.all_ok) return false;
+    const bool all_ok = sh.all_ok != 0;
+    lds_sync(); // (whoever goes on to resolve_tile sets the flag again: not before everyone has read it)
+    if (!all_ok) return false;
     sh.reach[lane] = mask ? 1 : 0;
     if (lane == 0) {
         sh.first_guess = first_guess;
@@ -424,6 +429,9 @@ __device__ inline bool resolve_tile_text(PbShared& sh, const Tile& t, uint32_t e
     lds_sync();
     return true;
 }
+
+// Where the tiles' record-start masks lie in a page's scratch: behind the tiles' and the page's words.
+__device__ inline gptr<uint32_t> masks_of(gptr<uint32_t> words, uint64_t tiles) { return words + tiles * TW_WORDS + PW_WORDS; }
 
 // Pass one: every tile from its own guess.
 __global__ __launch_bounds__(PT) void plain_bytes_guess_kernel(const DevPage* __restrict__ pages, const uint32_t* __restrict__ items) {
@@ -438,6 +446,13 @@ __global__ __launch_bounds__(PT) void plain_bytes_guess_kernel(const DevPage* __
         stage_tile(sh, t);
         lds_sync();
         if (!resolve_tile_text(sh, t, tile == 0 ? 0u : P_NONE)) resolve_tile(sh, t, tile == 0 ? 0u : P_NONE);
+        {
+            // the record starts of the chain, a bit per byte: the last pass takes them from here when the chain
+            // does enter the tile where this pass assumed
+            const unsigned long long mine = sh.reach[threadIdx.x] ? sh.starts[threadIdx.x] : 0;
+            u32x2_a4 m2 = {(uint32_t)mine, (uint32_t)(mine >> 32)};
+            *(gptr<u32x2_a4>)(masks_of(words, tiles) + (tile * PT + threadIdx.x) * 2) = m2;
+        }
         if (threadIdx.x == 0) {
             gptr<uint32_t> w = words + tile * TW_WORDS;
             const uint32_t type = sh.term_type;
@@ -573,10 +588,31 @@ __global__ __launch_bounds__(PT) void plain_bytes_copy_kernel(const DevPage* __r
         const Tile t = make_tile(pg, tile);
         gptr<const uint32_t> w = words + tile * TW_WORDS;
         const uint32_t entry = w[TW_ENTRY], rank0 = w[TW_RANK], prev0 = w[TW_PREV];
+        const bool as_guessed = entry != P_NONE && entry == w[TW_GUESS] && w[TW_FLAGS] == 0;
+        u32x2_a4 saved = {0, 0};
+        if (as_guessed) saved = *(gptr<const u32x2_a4>)(masks_of(words, tiles) + (tile * PT + lane) * 2);
         lds_sync();
         stage_tile(sh, t);
         lds_sync();
-        if (entry != P_NONE) {
+        if (as_guessed) {
+            // the first pass walked this very chain: its record starts, and for every sub-chunk where the record
+            // after its last one starts -- the first start in a later sub-chunk, or where the tile's chain ends
+            const unsigned long long mine = (unsigned long long)saved.x | (unsigned long long)saved.y << 32;
+            uint32_t first = mine ? lane * PSUB + (uint32_t)__builtin_ctzll(mine) : P_NONE;
+            uint32_t after = first; // least `first` of this lane and the later ones of the wavefront
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = (uint32_t)__shfl_down((int)after, d);
+                if ((lane & 63) + d < 64 && o < after) after = o;
+            }
+            if ((lane & 63) == 0) sh.part[0][lane >> 6] = after;
+            uint32_t later = (uint32_t)__shfl_down((int)after, 1);
+            if ((lane & 63) == 63) later = P_NONE;
+            lds_sync();
+            for (uint32_t wv = PT / 64 - 1; wv > (lane >> 6); wv--) later = std::min(later, sh.part[0][wv]);
+            sh.starts[lane] = mine;
+            sh.exit_[lane] = later != P_NONE ? later : w[TW_EXIT] - (uint32_t)t.base;
+            lds_sync();
+        } else if (entry != P_NONE) {
             if (!resolve_tile_text(sh, t, entry - (uint32_t)t.base)) resolve_tile(sh, t, entry - (uint32_t)t.base);
         }
         else { sh.starts[lane] = 0; sh.reach[lane] = 0; lds_sync(); }
@@ -631,45 +667,61 @@ __global__ __launch_bounds__(PT) void plain_bytes_copy_kernel(const DevPage* __r
         }
         lds_sync();
         // ---- the copy: a thread takes 16 bytes of the tile at a time, neighbours take neighbouring bytes ----
+        // (page positions and output positions fit 32 bits on this path; so does the capacity that matters)
+        const uint32_t cap32 = dst_cap > 0xffffffffull ? 0xffffffffu : (uint32_t)dst_cap, vend = (uint32_t)valid_end;
         for (uint32_t c16 = lane; c16 * 16 < t.bytes; c16 += PT) {
             const uint32_t at = c16 * 16, sub = at / PSUB, sh_bits = at % PSUB;
             const unsigned long long st = sh.starts[sub], hd = sh.headers[sub];
+            const u32x4 v = *reinterpret_cast<const u32x4*>(&sh.stage[at / 4]);
             const uint32_t st16 = (uint32_t)(st >> sh_bits) & 0xffffu, hd16 = (uint32_t)(hd >> sh_bits) & 0xffffu;
             // records that start before byte `at`
-            uint64_t k = (uint64_t)rank0 + sh.before[sub] + (uint32_t)__builtin_popcountll(st & ((1ull << sh_bits) - 1));
-            const uint64_t q = t.base + at;
+            const uint32_t k = rank0 + sh.before[sub] + (uint32_t)__builtin_popcountll(st & ((1ull << sh_bits) - 1));
+            const uint32_t q = (uint32_t)t.base + at;
             const uint32_t have = std::min<uint32_t>(16, t.bytes - at);
-            const bool whole = have == 16 && q + 16 <= valid_end;
+            const bool whole = have == 16 && q + 16 <= vend;
+            const uint32_t out = q - 4 * k; // (k records before `at` take 4 k bytes of fields before it: never negative)
             if (whole && hd16 == 0) {
                 // sixteen bytes of one value
-                const uint64_t out = q - 4 * k;
-                if (k > 0 && out + 16 <= dst_cap) {
-                    *(gptr<u32x4_a1>)(dst + out) = *reinterpret_cast<const u32x4*>(&sh.stage[at / 4]);
+                if (k > 0 && out <= cap32 && cap32 - out >= 16) {
+                    *(gptr<u32x4_a1>)(dst + out) = v;
                     continue;
                 }
-            } else if (whole && __builtin_popcount(st16) == 1 && __builtin_popcount(hd16) == 4 && (hd16 >> __builtin_ctz(st16)) == 0xfu) {
-                // one whole length field inside: the twelve bytes around it close up, still on a 4-byte grid
-                const uint32_t h = (uint32_t)__builtin_ctz(st16);
-                const uint64_t out = q - 4 * k;
-                if ((k > 0 || h == 0) && out + 12 <= dst_cap) {
-                    const u32x4 v = *reinterpret_cast<const u32x4*>(&sh.stage[at / 4]);
-                    const unsigned __int128 x = (unsigned __int128)v.x | (unsigned __int128)v.y << 32 | (unsigned __int128)v.z << 64 |
-                                                (unsigned __int128)v.w << 96;
-                    const unsigned __int128 low = h ? x & (((unsigned __int128)1 << (8 * h)) - 1) : 0;
-                    const unsigned __int128 high = h < 12 ? (x >> (8 * h + 32)) << (8 * h) : 0;
-                    const unsigned __int128 r = low | high;
+            } else if (whole && st16 != 0 && hd16 == (0xfu << __builtin_ctz(st16)) && (st16 & (st16 - 1)) == 0) {
+                // one whole length field inside: the twelve bytes around it close up.  The field is a dword long, so
+                // the dwords behind it move up by one as they are; only the one it starts in is put together of two
+                const uint32_t h = (uint32_t)__builtin_ctz(st16), j = h >> 2;
+                if ((k > 0 || h == 0) && out <= cap32 && cap32 - out >= 12) {
+                    const uint32_t low = (1u << (8 * (h & 3))) - 1; // bytes of dword j in front of the field
                     u32x3_a1 o;
-                    o.x = (uint32_t)r; o.y = (uint32_t)(r >> 32); o.z = (uint32_t)(r >> 64);
+                    o.x = j == 0 ? (v.x & low) | (v.y & ~low) : v.x;
+                    o.y = j == 0 ? v.z : (j == 1 ? (v.y & low) | (v.z & ~low) : v.y);
+                    o.z = j <= 1 ? v.w : (j == 2 ? (v.z & low) | (v.w & ~low) : v.z);
                     *(gptr<u32x3_a1>)(dst + out) = o;
                     continue;
                 }
             }
-            const uint8_t* bytes = reinterpret_cast<const uint8_t*>(sh.stage) + at;
-            for (uint32_t i = 0; i < have; i++) {
-                if (st16 >> i & 1) k++;
-                if ((hd16 >> i & 1) || k == 0 || q + i >= valid_end) continue;
-                const uint64_t out = q + i - 4 * k;
-                if (out < dst_cap) dst[out] = bytes[i];
+            // anything else: the bytes between length fields, a stretch at a time, each in at most four stores
+            uint32_t keep = ~hd16 & (have == 16 ? 0xffffu : (1u << have) - 1);
+            if (q + have > vend) keep &= q < vend ? (1u << (vend - q)) - 1 : 0u;
+            if (k == 0) keep &= st16 ? ~((1u << __builtin_ctz(st16)) - 1) : 0u; // bytes in front of the page's first record
+            if (!keep) continue;
+            const unsigned long long x_lo = (unsigned long long)v.x | (unsigned long long)v.y << 32;
+            const unsigned long long x_hi = (unsigned long long)v.z | (unsigned long long)v.w << 32;
+            while (keep) {
+                const uint32_t a = (uint32_t)__builtin_ctz(keep);
+                uint32_t run = (uint32_t)__builtin_ctz(~(keep >> a));
+                keep &= ~(((1u << run) - 1) << a);
+                const uint32_t o = q + a - 4 * (k + (uint32_t)__builtin_popcount(st16 & ((1u << a) - 1)));
+                if (o >= cap32) continue;
+                if (cap32 - o < run) run = cap32 - o;
+                // the stretch's bytes, from bit 0 on (run <= 15: sixteen whole bytes went the first way or have a field inside)
+                unsigned long long w0 = a == 0 ? x_lo : (a < 8 ? (x_lo >> (8 * a)) | (x_hi << (64 - 8 * a)) : x_hi >> (8 * (a - 8)));
+                const unsigned long long w1 = a < 8 ? x_hi >> (8 * a) : 0;
+                gptr<uint8_t> d = dst + o;
+                if (run & 8) { *(gptr<u64_a1>)d = w0; d += 8; w0 = w1; }
+                if (run & 4) { *(gptr<u32_a1>)d = (uint32_t)w0; d += 4; w0 >>= 32; }
+                if (run & 2) { *(gptr<u16_a1>)d = (uint16_t)w0; d += 2; w0 >>= 16; }
+                if (run & 1) *d = (uint8_t)w0;
             }
         }
     }
@@ -723,7 +775,7 @@ __global__ void plain_bytes_finish_kernel(const DevPage* __restrict__ pages, Dev
 uint64_t plain_bytes_scratch_words(uint64_t src_len) {
     // pages this path does not take: positions are kept in 32 bits
     if (src_len == 0 || src_len > 0xfff00000ull) return 0;
-    return ((src_len + PTILE - 1) / PTILE) * TW_WORDS + PW_WORDS;
+    return ((src_len + PTILE - 1) / PTILE) * (TW_WORDS + 2 * PT) + PW_WORDS;
 }
 
 void launch_plain_byte_array(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_bytes,

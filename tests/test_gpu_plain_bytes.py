@@ -133,3 +133,17 @@ def _walk(values, cap, ocap):
     if nv + 1 > ocap:
         return 18, nv + 1, nv, out
     return 0, 0, nv, out
+
+
+def test_tiled_decode_is_repeatable():
+    # tiles that the quick look at zero bytes settles and tiles that need the walk, side by side in one batch,
+    # several times over: the two ways of resolving a tile share LDS words
+    P = pkg()
+    rng = np.random.default_rng(22)
+    cases = _pages(rng)
+    specs = [spec(P.ENC.PLAIN, P.KIND.BYTE_ARRAY, _page(values), misalign=k % 16, dst_cap=len(_page(values)), offsets_cap=len(values) + 1)
+             for k, (label, values) in enumerate(cases)]
+    for trip in range(6):
+        for (label, values), out in zip(cases, _decode(True, specs)):
+            assert out.status == 0 and out.out_values == len(values), (trip, label)
+            assert out.data.tobytes() == b"".join(values), (trip, label)

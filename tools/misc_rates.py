@@ -184,6 +184,11 @@ def main():
     run("DELTA_LENGTH_BYTE_ARRAY urls (4 Ki)", [dlba_page(v) for v in small], 128, E.DELTA_LENGTH_BYTE_ARRAY, K.BYTE_ARRAY, 0, snb, 4096, sj)
     run("DELTA_BYTE_ARRAY urls (4 Ki)", [dba_page(v) for v in small], 128, E.DELTA_BYTE_ARRAY, K.BYTE_ARRAY, 0, snb, 4096, sj, steps=5)
     run("PLAIN byte arrays urls (4 Ki)", [plain_ba_page(v) for v in small], 128, E.PLAIN, K.BYTE_ARRAY, 0, snb, 4096, sj, steps=5)
+    # and into very many very small ones
+    tiny = [strings(rng, 512) for _ in range(64)]
+    tj = [np.frombuffer(b"".join(v), np.uint8) for v in tiny]
+    tnb = max(j.size for j in tj)
+    run("PLAIN byte arrays urls (512)", [plain_ba_page(v) for v in tiny], 256, E.PLAIN, K.BYTE_ARRAY, 0, tnb, 512, tj, steps=5)
 
 
 if __name__ == "__main__":
