@@ -583,6 +583,8 @@ __global__ __launch_bounds__(PT) void plain_bytes_copy_kernel(const DevPage* __r
     const uint64_t dst_cap = pg.dst_cap, offsets_cap = pg.offsets_cap;
     const uint32_t lane = threadIdx.x;
     const uint64_t valid_end = page[PW_END];  // bytes from here on belong to no record
+    // records [0, off_room) have room for their offset and the one after it; record off_room is the first that has not
+    const uint32_t off_room = offsets_cap >= 0x100000000ull ? 0xffffffffu : (uint32_t)(std::max<uint64_t>(offsets_cap, 1) - 1);
     const uint32_t total = page[PW_COUNT];
     for (uint64_t tile = blockIdx.y; tile < tiles; tile += gridDim.y) {
         const Tile t = make_tile(pg, tile);
@@ -634,13 +636,14 @@ __global__ __launch_bounds__(PT) void plain_bytes_copy_kernel(const DevPage* __r
             while (m && k < total) {                // (the record that failed is not one)
                 const uint32_t bit = (uint32_t)__builtin_ctzll(m);
                 m &= m - 1;
-                const uint64_t pos = t.base + lane * PSUB + bit;
-                const uint64_t next = t.base + (m ? lane * PSUB + (uint32_t)__builtin_ctzll(m) : sh.exit_[lane]);
-                const uint64_t out = pos - 4ull * k, len = next - pos - 4;
-                if ((uint64_t)k + 2 <= offsets_cap) offsets[k] = (uint32_t)out;
-                else if ((uint64_t)k + 1 == std::max<uint64_t>(offsets_cap, 1)) { page[PW_OFF_OUT] = (uint32_t)out; page[PW_OFF_POS] = (uint32_t)pos; }
-                if (out <= dst_cap && out + len > dst_cap) {
-                    page[PW_DST_RANK] = k; page[PW_DST_OUT] = (uint32_t)out; page[PW_DST_LEN] = (uint32_t)len; page[PW_DST_POS] = (uint32_t)pos;
+                // (positions, and so output positions and lengths, fit 32 bits on this path)
+                const uint32_t pos = (uint32_t)t.base + lane * PSUB + bit;
+                const uint32_t next = (uint32_t)t.base + (m ? lane * PSUB + (uint32_t)__builtin_ctzll(m) : sh.exit_[lane]);
+                const uint32_t out = pos - 4 * k, len = next - pos - 4;
+                if (k < off_room) offsets[k] = out;
+                else if (k == off_room) { page[PW_OFF_OUT] = out; page[PW_OFF_POS] = pos; }
+                if (out <= dst_cap && (uint64_t)out + len > dst_cap) {
+                    page[PW_DST_RANK] = k; page[PW_DST_OUT] = out; page[PW_DST_LEN] = len; page[PW_DST_POS] = pos;
                 }
                 k++;
             }
@@ -686,18 +689,41 @@ __global__ __launch_bounds__(PT) void plain_bytes_copy_kernel(const DevPage* __r
                     *(gptr<u32x4_a1>)(dst + out) = v;
                     continue;
                 }
-            } else if (whole && st16 != 0 && hd16 == (0xfu << __builtin_ctz(st16)) && (st16 & (st16 - 1)) == 0) {
-                // one whole length field inside: the twelve bytes around it close up.  The field is a dword long, so
-                // the dwords behind it move up by one as they are; only the one it starts in is put together of two
-                const uint32_t h = (uint32_t)__builtin_ctz(st16), j = h >> 2;
-                if ((k > 0 || h == 0) && out <= cap32 && cap32 - out >= 12) {
-                    const uint32_t low = (1u << (8 * (h & 3))) - 1; // bytes of dword j in front of the field
-                    u32x3_a1 o;
-                    o.x = j == 0 ? (v.x & low) | (v.y & ~low) : v.x;
-                    o.y = j == 0 ? v.z : (j == 1 ? (v.y & low) | (v.z & ~low) : v.y);
-                    o.z = j <= 1 ? v.w : (j == 2 ? (v.z & low) | (v.w & ~low) : v.z);
-                    *(gptr<u32x3_a1>)(dst + out) = o;
-                    continue;
+            } else if (whole) {
+                // One length field, or a part of one at either end of the sixteen bytes: what is left is one
+                // stretch of 12 to 15 bytes.  A whole field is a dword long, so the dwords behind it move up by one as
+                // they are and only the dword it starts in is put together of two; a part of a field at the front
+                // shifts everything down by its bytes; one at the back takes nothing but the count down.
+                const uint32_t h0 = (uint32_t)__builtin_ctz(hd16), L = (uint32_t)__builtin_ctz(~(hd16 >> h0));
+                const bool one_run = (hd16 >> h0) == (1u << L) - 1;
+                const bool inside = L == 4 && st16 == (1u << h0);                  // a whole field, begun here
+                const bool front = h0 == 0 && L < 4 && st16 == 0;                  // the end of a field begun before
+                const bool back = h0 + L == 16 && L < 4 && st16 == (1u << h0);     // the beginning of one that goes on
+                if (one_run && (inside || front || back) && (k > 0 || (h0 == 0 && !front))) {
+                    u32x4 o = v;
+                    uint32_t first = out; // where the stretch goes
+                    if (inside) {
+                        const uint32_t j = h0 >> 2, low = (1u << (8 * (h0 & 3))) - 1; // bytes of dword j in front of the field
+                        o.x = j == 0 ? (v.x & low) | (v.y & ~low) : v.x;
+                        o.y = j == 0 ? v.z : (j == 1 ? (v.y & low) | (v.z & ~low) : v.y);
+                        o.z = j <= 1 ? v.w : (j == 2 ? (v.z & low) | (v.w & ~low) : v.z);
+                    } else if (front) {
+                        o.x = __builtin_amdgcn_alignbyte(v.y, v.x, L);
+                        o.y = __builtin_amdgcn_alignbyte(v.z, v.y, L);
+                        o.z = __builtin_amdgcn_alignbyte(v.w, v.z, L);
+                        o.w = v.w >> (8 * L);
+                        first = out + L; // q + L - 4 k: the field's record is among the k
+                    }
+                    const uint32_t n = 16 - L; // 12 when inside, else 13 .. 15
+                    if (first <= cap32 && cap32 - first >= n) {
+                        gptr<uint8_t> d = dst + first;
+                        u32x3_a1 o3 = {o.x, o.y, o.z};
+                        *(gptr<u32x3_a1>)d = o3;
+                        uint32_t rest = o.w;
+                        if (n & 2) { *(gptr<u16_a1>)(d + 12) = (uint16_t)rest; rest >>= 16; }
+                        if (n & 1) d[12 + (n & 2)] = (uint8_t)rest;
+                        continue;
+                    }
                 }
             }
             // anything else: the bytes between length fields, a stretch at a time, each in at most four stores
