@@ -170,14 +170,50 @@ template <> struct DeltaOf<int64_t> {
 
 struct DeltaShared {
     uint32_t size[DE_TILE_BLOCKS];   // encoded bytes of each block of the tile
-    uint32_t head;                   // bytes of the page header (first tile of a page)
+    uint32_t at[DE_TILE_BLOCKS];     // where each block starts in the staging area
+    uint32_t total;                  // bytes of the tile
     uint64_t before;                 // bytes of the page in front of this tile
     // worst case per block: 10 (min delta) + 4 (widths) + 128 * 8; header: 2 + 1 + 10 + 10; two spare dwords
     uint32_t stage[(DE_TILE_BLOCKS * (14 + DE_BLOCK * 8) + 24) / 4 + 4];
 };
 
+// Eight neighbouring values of a block from src + k0, or zeros where the page has ended.
+template <typename T>
+__device__ inline void load_eight(gptr<const T> src, uint64_t k0, uint64_t n, T (&x)[8]) {
+    if (k0 + 8 <= n) {
+        if (sizeof(T) == 8) {
+#pragma unroll
+            for (uint32_t i = 0; i < 4; i++) { // a Go []int64 is 8-byte aligned
+                const u64x2_a8 q = *(gptr<const u64x2_a8>)(src + k0 + 2 * i);
+                x[2 * i] = (T)q.x; x[2 * i + 1] = (T)q.y;
+            }
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < 2; i++) {
+                const u32x4_a4 q = *(gptr<const u32x4_a4>)(src + k0 + 4 * i);
+                x[4 * i] = (T)q.x; x[4 * i + 1] = (T)q.y; x[4 * i + 2] = (T)q.z; x[4 * i + 3] = (T)q.w;
+            }
+        }
+    } else {
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) x[i] = k0 + i < n ? src[k0 + i] : (T)0;
+    }
+}
+
+// stage_or for a field of at most 32 bits: two dwords at most.
+__device__ inline void stage_or32(uint32_t* stage, uint32_t at, uint32_t v) {
+    const uint32_t w = at >> 5, s = at & 31;
+    const uint64_t x = (uint64_t)v << s;
+    const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32);
+    if (x0) atomicOr(&stage[w], x0);
+    if (x1) atomicOr(&stage[w + 1], x1);
+}
+
 // One workgroup encodes up to 16 blocks (binary_packed.go:105-176): every wavefront takes four
-// of them, a lane two neighbouring values of a block.
+// of them at once, sixteen lanes to a block, a lane eight neighbouring values -- a quarter of a
+// miniblock, whose packed form is a whole number of bytes.  (With two values to a lane and the
+// blocks one after the other the reductions over the lanes were most of the kernel, which spent
+// a hundred vector instructions per value and was bound by issuing them.)
 template <typename T>
 __global__ __launch_bounds__(ET) void delta_encode_kernel(EncPage* __restrict__ pages, const uint32_t* __restrict__ items,
                                                           const uint64_t* __restrict__ prefix, uint32_t n_pages,
@@ -194,55 +230,63 @@ __global__ __launch_bounds__(ET) void delta_encode_kernel(EncPage* __restrict__ 
     const uint32_t blocks = (uint32_t)std::min<uint64_t>(DE_TILE_BLOCKS, n_blocks - std::min(n_blocks, block0));
 
     constexpr uint32_t PER_WAVE = DE_TILE_BLOCKS / (ET / 64);
-    uint64_t r0[PER_WAVE], r1[PER_WAVE];
-    int64_t min_delta[PER_WAVE];
-    uint32_t widths[PER_WAVE]; // the four miniblock widths of the block, a byte each
-#pragma unroll
-    for (uint32_t j = 0; j < PER_WAVE; j++) {
-        const uint32_t b = wave * PER_WAVE + j;
-        r0[j] = r1[j] = 0; min_delta[j] = 0; widths[j] = 0;
-        if (b >= blocks) continue;
-        const uint64_t k0 = 1 + (block0 + b) * DE_BLOCK + 2 * lane; // index of the lane's first value
+    static_assert(PER_WAVE * 16 == 64 && DE_BLOCK == 16 * 8 && DE_MINI == 4 * 8, "sixteen lanes to a block, four to a miniblock");
+    const uint32_t l = lane & 15;                  // lane within its block
+    const uint32_t b = wave * PER_WAVE + (lane >> 4); // the lane's block of the tile
+    const bool live = b < blocks;
+    uint64_t r[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // the lane's differences, less the block's least
+    int64_t min_delta = 0;
+    uint32_t widths = 0;                           // the four miniblock widths of the block, a byte each
+    {
+        const uint64_t k0 = 1 + (block0 + b) * DE_BLOCK + 8 * l; // index of the lane's first value
+        // values of the page from k0 on, as far as it matters here: value i of the lane exists when i < left, and
+        // its difference counts when i <= left (the first zero of the padding is a difference too)
+        const uint32_t left = !live || k0 > n ? 0u : (uint32_t)std::min<uint64_t>(n - k0, 16);
+        const bool counted = live && k0 <= n;
+        T x[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        T prev = 0;
+        if (live && n > 0) {
+            prev = src[std::min(k0 - 1, n - 1)];
+            load_eight<T>(src, k0, n, x);
+        }
         // the block is padded with zeros before the differences and their minimum are taken (binary_packed.go:139-146)
-        const T prev = src[std::min(k0 - 1, n - 1)];
-        const T v0 = k0 < n ? src[k0] : (T)0;
-        const T v1 = k0 + 1 < n ? src[k0 + 1] : (T)0;
-        const int64_t d0 = k0 <= n ? DeltaOf<T>::diff(v0, prev) : 0;
-        const int64_t d1 = k0 + 1 <= n ? DeltaOf<T>::diff(v1, v0) : 0;
-        int64_t m = std::min(d0, d1);
-        for (int o = 32; o > 0; o >>= 1) m = std::min(m, (int64_t)__shfl_xor((long long)m, o));
-        r0[j] = k0 < n ? DeltaOf<T>::rebase(d0, m) : 0;
-        r1[j] = k0 + 1 < n ? DeltaOf<T>::rebase(d1, m) : 0;
-        uint64_t any = r0[j] | r1[j];
-        for (int o = 8; o > 0; o >>= 1) any |= __shfl_xor((unsigned long long)any, o); // the sixteen lanes of a miniblock
-        const uint32_t bw = bits_len64(any);
-        uint32_t w = 0;
+        int64_t d[8];
 #pragma unroll
-        for (uint32_t mb = 0; mb < 4; mb++) w |= lane_u32(bw, 16 * mb) << (8 * mb);
-        widths[j] = w;
-        min_delta[j] = m;
-        if (lane == 0)
-            sh.size[b] = uvarint_len(zigzag(m)) + 4 + 4 * ((w & 0xff) + ((w >> 8) & 0xff) + ((w >> 16) & 0xff) + (w >> 24));
+        for (uint32_t i = 0; i < 8; i++) d[i] = counted && i <= left ? DeltaOf<T>::diff(x[i], i == 0 ? prev : x[i - 1]) : 0;
+        int64_t m = d[0];
+#pragma unroll
+        for (uint32_t i = 1; i < 8; i++) m = std::min(m, d[i]);
+        for (int o = 8; o > 0; o >>= 1) m = std::min(m, (int64_t)__shfl_xor((long long)m, o)); // the sixteen lanes of the block
+        uint64_t any = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < 8; i++) {
+            r[i] = i < left ? DeltaOf<T>::rebase(d[i], m) : 0;
+            any |= r[i];
+        }
+        for (int o = 2; o > 0; o >>= 1) any |= __shfl_xor((unsigned long long)any, o);         // the four lanes of the miniblock
+        const uint32_t bw = bits_len64(any);
+#pragma unroll
+        for (uint32_t mb = 0; mb < 4; mb++) widths |= (uint32_t)__shfl((int)bw, (int)((lane & 48) + 4 * mb)) << (8 * mb);
+        min_delta = m;
+        if (live && l == 0)
+            sh.size[b] = uvarint_len(zigzag(m)) + 4 + 4 * ((widths & 0xff) + ((widths >> 8) & 0xff) + ((widths >> 16) & 0xff) + (widths >> 24));
     }
     const T first = n > 0 ? src[0] : (T)0;
-    if (threadIdx.x == 0)
-        sh.head = tile == 0 ? 2 + 1 + uvarint_len(n) + uvarint_len(zigzag((int64_t)first)) : 0;
-    for (uint32_t i = threadIdx.x; i < sizeof(sh.stage) / 4; i += ET) sh.stage[i] = 0;
+    const uint32_t head = tile == 0 ? 2 + 1 + uvarint_len(n) + uvarint_len(zigzag((int64_t)first)) : 0;
     lds_sync();
-    uint32_t at[PER_WAVE]; // where each of the wave's blocks starts in the staging area
-    uint32_t total = sh.head;
-    {
-        uint32_t run = sh.head;
-#pragma unroll
-        for (uint32_t j = 0; j < PER_WAVE; j++) at[j] = 0;
-#pragma unroll
-        for (uint32_t b = 0; b < DE_TILE_BLOCKS; b++) {
-#pragma unroll
-            for (uint32_t j = 0; j < PER_WAVE; j++) at[j] = b == wave * PER_WAVE + j ? run : at[j];
-            if (b < blocks) run += sh.size[b];
-        }
-        total = run;
+    // where every block starts in the staging area: a scan over sixteen lanes
+    if (wave == 0) {
+        const uint32_t mine = lane < blocks ? sh.size[lane] : 0;
+        const uint32_t incl = wave_inclusive_scan<uint32_t>(mine);
+        if (lane < DE_TILE_BLOCKS) sh.at[lane] = head + incl - mine;
+        if (lane == 63) sh.total = head + incl;
     }
+    lds_sync();
+    const uint32_t total = sh.total;
+    // fields are ORed into the staging area: what will be used of it starts out as zeros
+    for (uint32_t i = threadIdx.x; i < (total + 3) / 4 + 2; i += ET) sh.stage[i] = 0;
+    lds_sync();
+    const uint32_t at = sh.at[b]; // where the lane's block starts in the staging area
     if (wave == 0) {
         const uint64_t before = tile_prefix(state + pg.tile_base, tile, total, lane);
         if (lane == 0) sh.before = before;
@@ -254,24 +298,26 @@ __global__ __launch_bounds__(ET) void delta_encode_kernel(EncPage* __restrict__ 
         o += stage_uvarint(sh.stage, o, n);
         o += stage_uvarint(sh.stage, o, zigzag((int64_t)first));
     }
-#pragma unroll
-    for (uint32_t j = 0; j < PER_WAVE; j++) {
-        const uint32_t b = wave * PER_WAVE + j;
-        if (b >= blocks) continue;
-        const uint32_t w = widths[j];
-        uint32_t o = at[j];
-        const uint32_t vl = uvarint_len(zigzag(min_delta[j]));
-        if (lane == 0) {
-            stage_uvarint(sh.stage, o, zigzag(min_delta[j]));
+    if (live) {
+        const uint32_t w = widths;
+        uint32_t o = at;
+        const uint32_t vl = uvarint_len(zigzag(min_delta));
+        if (l == 0) {
+            stage_uvarint(sh.stage, o, zigzag(min_delta));
             stage_or(sh.stage, 8ull * (o + vl), w, 32);
         }
         o += vl + 4;
-        const uint32_t mb = lane >> 4;
+        const uint32_t mb = l >> 2;
         const uint32_t bw = (w >> (8 * mb)) & 0xff;
         for (uint32_t q = 0; q < mb; q++) o += 4 * ((w >> (8 * q)) & 0xff);
-        const uint64_t bit = 8ull * o + (uint64_t)(2 * (lane & 15)) * bw;
-        stage_or(sh.stage, bit, r0[j], bw);
-        stage_or(sh.stage, bit + bw, r1[j], bw);
+        const uint32_t bit = 8 * o + 8 * (l & 3) * bw; // eight values of bw bits: bw bytes per lane
+        if (bw <= 32) {
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++) stage_or32(sh.stage, bit + i * bw, (uint32_t)r[i]);
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < 8; i++) stage_or(sh.stage, bit + i * bw, r[i], bw);
+        }
     }
     lds_sync();
     const uint64_t before = sh.before;

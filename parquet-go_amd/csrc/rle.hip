@@ -1106,6 +1106,9 @@ __device__ __forceinline__ void expand_runs_bytes(const u32x4* tab, uint32_t nr,
     }
 }
 
+__device__ __forceinline__ void page_expand(const u32x4* tab, uint32_t nr, const uint32_t* win, int64_t base, const DevPage& pg, uint32_t G0,
+                                   uint32_t G1, uint32_t bw);
+
 // One-byte outputs (levels, booleans): a whole group of steps at once.  The runs that meet the
 // group are copied to LDS in one go, the packed bytes of all its bit-packed runs in another,
 // and the runs are then expanded one after the other out of LDS: three dependent round trips
@@ -1167,7 +1170,12 @@ __device__ __forceinline__ bool expand_group_bytes(EShared& sh, const DevPage& p
             *reinterpret_cast<u32x4*>(&sh.stage[(c + GROUP_STAGE_PAD) >> 2]) = *(gptr<const u32x4>)(src + base + c);
     }
     __syncthreads();
-    expand_runs_bytes(tab, nr, sh.stage, base, pg, G0, GS, bw);
+    // Levels take the piece-by-piece form (every lane looks up the run of its sixteen bytes): the run-by-run
+    // form spends some thirty scalar instructions per run in every wavefront, and level runs are short.
+    if (pg.kind == PQD_KIND_LEVELS && bw >= 1 && bw <= 8 && G0 + GS <= 0xffffffffull)
+        page_expand(tab, nr, sh.stage, base, pg, (uint32_t)G0, (uint32_t)(G0 + GS), bw);
+    else
+        expand_runs_bytes(tab, nr, sh.stage, base, pg, G0, GS, bw);
     return true;
 }
 
@@ -1380,7 +1388,7 @@ __device__ inline u32x4 page_unpack16(const uint32_t* win, uint32_t e_y, int64_t
 // splat or unpacks its sixteen fields without looking anything up; otherwise every lane finds
 // the run of its piece in the table, and a piece that meets several runs, or the ragged ends of a
 // stretch, goes value by value.
-__device__ inline void page_expand(const u32x4* tab, uint32_t nr, const uint32_t* win, int64_t base, const DevPage& pg, uint32_t G0,
+__device__ __forceinline__ void page_expand(const u32x4* tab, uint32_t nr, const uint32_t* win, int64_t base, const DevPage& pg, uint32_t G0,
                                    uint32_t G1, uint32_t bw) {
     const uint32_t lane = threadIdx.x & 63, wave = pw_uniform(threadIdx.x >> 6);
     gptr<uint8_t> dst = as_global(pg.dst);
