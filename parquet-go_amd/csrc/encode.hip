@@ -155,6 +155,23 @@ __device__ inline uint32_t page_of_tile(const uint64_t* __restrict__ prefix, uin
     return lo;
 }
 
+// The page (its place in the family's list) and the tile of it that this workgroup takes; false when there is none.
+// Two grids: (tiles of all pages) with `prefix`, where the page is searched for -- a dozen dependent scalar loads
+// and some four hundred scalar instructions per wavefront, half of what a tile of 16 KB costs otherwise --, and
+// (most tiles a page has, pages) without, for batches whose pages are about equally long.  Either way the
+// workgroups of a page are numbered in the order of its tiles, which is what the look-back needs.
+__device__ inline bool page_and_tile(const EncPage* __restrict__ pages, const uint32_t* __restrict__ items,
+                                     const uint64_t* __restrict__ prefix, uint32_t n_pages, uint32_t& p, uint64_t& tile) {
+    if (prefix != nullptr) {
+        p = page_of_tile(prefix, n_pages, blockIdx.x);
+        tile = blockIdx.x - prefix[p];
+        return true;
+    }
+    p = blockIdx.y;
+    tile = blockIdx.x;
+    return tile < pages[items[p]].n_tiles;
+}
+
 // ---------------------------------------------------------- DELTA_BINARY_PACKED --
 
 template <typename T> struct DeltaOf;
@@ -205,8 +222,8 @@ __device__ inline void stage_or32(uint32_t* stage, uint32_t at, uint32_t v) {
     const uint32_t w = at >> 5, s = at & 31;
     const uint64_t x = (uint64_t)v << s;
     const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32);
-    if (x0) atomicOr(&stage[w], x0);
-    if (x1) atomicOr(&stage[w + 1], x1);
+    atomicOr(&stage[w], x0);     // (no test for zero: a branch costs more than the OR of nothing)
+    atomicOr(&stage[w + 1], x1);
 }
 
 // One workgroup encodes up to 16 blocks (binary_packed.go:105-176): every wavefront takes four
@@ -219,9 +236,10 @@ __global__ __launch_bounds__(ET) void delta_encode_kernel(EncPage* __restrict__ 
                                                           const uint64_t* __restrict__ prefix, uint32_t n_pages,
                                                           unsigned long long* __restrict__ state) {
     __shared__ DeltaShared sh;
-    const uint32_t p = page_of_tile(prefix, n_pages, blockIdx.x);
+    uint32_t p;
+    uint64_t tile;
+    if (!page_and_tile(pages, items, prefix, n_pages, p, tile)) return;
     EncPage& pg = pages[items[p]];
-    const uint64_t tile = blockIdx.x - prefix[p];
     gptr<const T> src = (gptr<const T>)pg.src;
     const uint64_t n = pg.n_values;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -422,9 +440,10 @@ struct RleEncShared {
 __global__ __launch_bounds__(ET) void rle_encode_scan_kernel(EncPage* __restrict__ pages, const uint32_t* __restrict__ items,
                                                              const uint64_t* __restrict__ prefix, uint32_t n_pages) {
     __shared__ uint32_t sh_first, sh_or;
-    const uint32_t p = page_of_tile(prefix, n_pages, blockIdx.x);
+    uint32_t p;
+    uint64_t tile;
+    if (!page_and_tile(pages, items, prefix, n_pages, p, tile)) return;
     EncPage& pg = pages[items[p]];
-    const uint64_t tile = blockIdx.x - prefix[p];
     gptr<const uint32_t> src = (gptr<const uint32_t>)pg.src;
     const uint64_t n = pg.n_values, groups = n / 8;
     const uint64_t g = tile * RE_GROUPS + threadIdx.x;
@@ -479,9 +498,10 @@ __global__ __launch_bounds__(ET) void rle_encode_write_kernel(EncPage* __restric
                                                               const uint64_t* __restrict__ prefix, uint32_t n_pages,
                                                               unsigned long long* __restrict__ state) {
     __shared__ RleEncShared sh;
-    const uint32_t p = page_of_tile(prefix, n_pages, blockIdx.x);
+    uint32_t p;
+    uint64_t tile;
+    if (!page_and_tile(pages, items, prefix, n_pages, p, tile)) return;
     EncPage& pg = pages[items[p]];
-    const uint64_t tile = blockIdx.x - prefix[p];
     gptr<const uint32_t> src = (gptr<const uint32_t>)pg.src;
     const uint64_t n = pg.n_values, groups = n / 8;
     const uint64_t g = tile * RE_GROUPS + threadIdx.x;
@@ -862,23 +882,38 @@ int pqd_encode_batch(pqd_ctx* ctx, pqd_encode_page* pages, uint64_t n_pages, voi
     unsigned long long* d_state = reinterpret_cast<unsigned long long*>(ws + plan.o_state);
     auto items_of = [&](int f) { return reinterpret_cast<const uint32_t*>(ws + plan.o_items[f]); };
     auto prefix_of = [&](int f) { return reinterpret_cast<const uint64_t*>(ws + plan.o_prefix[f]); };
+    // the grid of a family's tile kernels, and the prefix they search (none for the pages-by-tiles grid: see page_and_tile)
+    auto tile_grid = [&](int f, dim3& grid, const uint64_t*& prefix) {
+        const std::vector<uint64_t>& pre = plan.fam_prefix[f];
+        const uint64_t tiles = pre.back(), np = plan.fam_items[f].size();
+        uint64_t most = 0;
+        for (size_t k = 0; k + 1 < pre.size(); k++) most = std::max(most, pre[k + 1] - pre[k]);
+        if (np <= 65535 && most <= 0x7fffffffull && most * np <= tiles + tiles / 2) { grid = dim3((uint32_t)most, (uint32_t)np); prefix = nullptr; }
+        else { grid = dim3((uint32_t)tiles); prefix = prefix_of(f); }
+    };
     for (int f : {EF_DELTA32, EF_DELTA64}) {
         const uint64_t tiles = plan.fam_prefix[f].back();
         if (tiles == 0) continue;
         if (tiles > 0x7fffffffull) return PQD_ERR_INVALID_ARGUMENT;
         const uint32_t np = (uint32_t)plan.fam_items[f].size();
+        dim3 grid;
+        const uint64_t* prefix;
+        tile_grid(f, grid, prefix);
         if (f == EF_DELTA32)
-            hipLaunchKernelGGL(delta_encode_kernel<int32_t>, dim3((uint32_t)tiles), dim3(ET), 0, s, d_pages, items_of(f), prefix_of(f), np, d_state);
+            hipLaunchKernelGGL(delta_encode_kernel<int32_t>, grid, dim3(ET), 0, s, d_pages, items_of(f), prefix, np, d_state);
         else
-            hipLaunchKernelGGL(delta_encode_kernel<int64_t>, dim3((uint32_t)tiles), dim3(ET), 0, s, d_pages, items_of(f), prefix_of(f), np, d_state);
+            hipLaunchKernelGGL(delta_encode_kernel<int64_t>, grid, dim3(ET), 0, s, d_pages, items_of(f), prefix, np, d_state);
     }
     if (const uint64_t tiles = plan.fam_prefix[EF_RLE_DICT].back()) {
         if (tiles > 0x7fffffffull) return PQD_ERR_INVALID_ARGUMENT;
         const int f = EF_RLE_DICT;
         const uint32_t np = (uint32_t)plan.fam_items[f].size();
-        hipLaunchKernelGGL(rle_encode_scan_kernel, dim3((uint32_t)tiles), dim3(ET), 0, s, d_pages, items_of(f), prefix_of(f), np);
+        dim3 grid;
+        const uint64_t* prefix;
+        tile_grid(f, grid, prefix);
+        hipLaunchKernelGGL(rle_encode_scan_kernel, grid, dim3(ET), 0, s, d_pages, items_of(f), prefix, np);
         hipLaunchKernelGGL(rle_encode_next_kernel, dim3(np), dim3(64), 0, s, d_pages, items_of(f));
-        hipLaunchKernelGGL(rle_encode_write_kernel, dim3((uint32_t)tiles), dim3(ET), 0, s, d_pages, items_of(f), prefix_of(f), np, d_state);
+        hipLaunchKernelGGL(rle_encode_write_kernel, grid, dim3(ET), 0, s, d_pages, items_of(f), prefix, np, d_state);
     }
     if (!plan.fam_items[EF_BSS].empty()) {
         const uint64_t per = (uint64_t)ET * 4;
