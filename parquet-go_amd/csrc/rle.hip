@@ -1339,22 +1339,23 @@ __device__ inline uint32_t pw_advance(uint32_t a0, uint32_t p, uint32_t w_hi, ui
 }
 
 // Sixteen fields of BW bits out of the 128 bits x[0..3] (field i at bit i * BW), one byte each.
+// Four fields at a time: the 4 BW bits are cut out, their upper half moves up to bit 16, and the upper
+// field of either half up to its byte: two shift-and-merge steps for four fields, whatever the width.
 template <uint32_t BW>
 __device__ inline u32x4 page_fields16(const uint32_t (&x)[4]) {
     if (BW == 8) return u32x4{x[0], x[1], x[2], x[3]};
+    constexpr uint32_t M1 = (1u << BW) - 1, M2 = (1u << (2 * BW)) - 1, M4 = BW == 8 ? 0xffffffffu : (1u << (4 * BW)) - 1;
     uint32_t o[4];
 #pragma unroll
     for (uint32_t q = 0; q < 4; q++) {
-        uint32_t w = 0;
-#pragma unroll
-        for (uint32_t e = 0; e < 4; e++) {
-            const uint32_t bit = (q * 4 + e) * BW, k = bit >> 5, off = bit & 31;
-            uint32_t f;
-            if (off + BW <= 32) f = (x[k] >> off) & ((1u << BW) - 1);
-            else f = __builtin_amdgcn_alignbit(x[(k + 1) & 3], x[k], off) & ((1u << BW) - 1);
-            w |= f << (8 * e);
-        }
-        o[q] = w;
+        const uint32_t bit = q * 4 * BW, k = bit >> 5, off = bit & 31;
+        uint32_t t;
+        if (off + 4 * BW <= 32) t = x[k] >> off;
+        else t = __builtin_amdgcn_alignbit(x[(k + 1) & 3], x[k], off);
+        t &= M4;
+        t = (t & M2) | ((t << (16 - 2 * BW)) & (M2 << 16));
+        t = (t & (M1 * 0x00010001u)) | ((t << (8 - BW)) & (M1 * 0x01000100u));
+        o[q] = t;
     }
     return u32x4{o[0], o[1], o[2], o[3]};
 }
