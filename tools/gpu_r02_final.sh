@@ -1,5 +1,5 @@
 #!/bin/bash
-# round-2 measurement set: other encodings (rates + kernels), the sweeps, the wide table
+# the measurement set beside the bench line: other encodings (rates + kernels), the sweeps, the wide table
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02f; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 bash $R/tools/gpu_r02_misc.sh > $O/misc.log 2>&1 || { tail -20 $O/misc.log; exit 1; }

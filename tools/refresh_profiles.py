@@ -1,7 +1,7 @@
 """Copies what tools/gpu_round_check.sh left under gpurun_out/ into profiles/ (tracked):
 the bench line, the rocprofv3 kernel statistics of the same command, and the HBM traffic of
 the kernels per launch from the FETCH_SIZE / WRITE_SIZE counter passes (KiB; FETCH_SIZE
-doubled: gfx950 tallies 128-byte read requests at 64 bytes).  Usage: python tools/refresh_profiles.py r01_b"""
+doubled: gfx950 tallies 128-byte read requests at 64 bytes).  Usage: python tools/refresh_profiles.py <tag for the file names>"""
 import collections
 import csv
 import json
@@ -58,4 +58,6 @@ def main(tag):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1] if len(sys.argv) > 1 else "r01_b")
+    if len(sys.argv) < 2:
+        sys.exit("usage: python tools/refresh_profiles.py <tag for the file names>")
+    main(sys.argv[1])
