@@ -70,18 +70,9 @@ __device__ inline void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barr
 // Wavefront-wide least / greatest / sum, the same in every lane.  (An LDS atomic of all lanes on one address is
 // turned by the compiler into a loop over the lanes, half a dozen scalar instructions each: four of them per tile
 // and the compute unit's one scalar unit is what the kernel waits for.)
-__device__ inline uint32_t wave_least(uint32_t v) {
-    for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, d); v = o < v ? o : v; }
-    return v;
-}
-__device__ inline uint32_t wave_greatest(uint32_t v) {
-    for (int d = 32; d > 0; d >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)v, d); v = o > v ? o : v; }
-    return v;
-}
-__device__ inline uint32_t wave_total(uint32_t v) {
-    for (int d = 32; d > 0; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
-    return v;
-}
+__device__ inline uint32_t wave_least(uint32_t v) { return wave_least_u32(v); }
+__device__ inline uint32_t wave_greatest(uint32_t v) { return wave_greatest_u32(v); }
+__device__ inline uint32_t wave_total(uint32_t v) { return lane_u32(wave_inclusive_scan<uint32_t>(v), 63); }
 
 // sh.part[k] of the four wavefronts, combined; k as in the declaration.
 __device__ inline uint32_t part_least(const PbShared& sh, uint32_t k) {
