@@ -52,11 +52,18 @@ typedef uint32_t u32_a1 __attribute__((aligned(1)));
 struct PbShared {
     alignas(16) uint32_t stage[(PTILE + PLOOK) / 4 + 16];
     unsigned long long starts[PT];  // per byte of a lane's sub-chunk: a record starts here
-    unsigned long long headers[PT]; // ... the byte belongs to a length field
-    uint32_t exits[PT * 2];         // per byte of the tile: some lane's walk ended here
     uint32_t guess[PT];             // tile position where a lane starts, or P_NONE
     uint32_t exit_[PT];             // tile position where the lane's walk ended (the failing record's, when it failed)
-    uint16_t hop[8][PT];            // lane reached after 1, 2, 4 ... links (or T_*)
+    // Never alive together (a barrier lies between the last use of one and the first of the next): the marks
+    // while the walks are checked against each other, the hops while the links are followed, the length-field
+    // bytes while the tile is copied.  4 KB less, and a compute unit holds six workgroups instead of five.
+    union {
+        uint16_t hop[8][PT];        // lane reached after 1, 2, 4 ... links (or T_*)
+        struct {
+            uint32_t exits[PT * 2];         // per byte of the tile: some lane's walk ended here
+            unsigned long long headers[PT]; // per byte of a lane's sub-chunk: the byte belongs to a length field
+        };
+    };
     uint16_t before[PT];            // records of the tile that start before the sub-chunk
     uint8_t err[PT];
     uint8_t reach[PT];
@@ -425,7 +432,7 @@ __device__ inline bool resolve_tile_text(PbShared& sh, const Tile& t, uint32_t e
 __device__ inline gptr<uint32_t> masks_of(gptr<uint32_t> words, uint64_t tiles) { return words + tiles * TW_WORDS + PW_WORDS; }
 
 // Pass one: every tile from its own guess.
-__global__ __launch_bounds__(PT) void plain_bytes_guess_kernel(const DevPage* __restrict__ pages, const uint32_t* __restrict__ items) {
+__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void plain_bytes_guess_kernel(const DevPage* __restrict__ pages, const uint32_t* __restrict__ items) {
     __shared__ PbShared sh;
     const DevPage& pg = pages[items[blockIdx.x]];
     if (pg.lengths == nullptr) return; // left to the one-wavefront walker
@@ -561,7 +568,7 @@ __global__ __launch_bounds__(64) void plain_bytes_chain_kernel(const DevPage* __
 }
 
 // Pass three: the tiles again from their true entries; offsets and bytes.
-__global__ __launch_bounds__(PT) void plain_bytes_copy_kernel(const DevPage* __restrict__ pages, const uint32_t* __restrict__ items) {
+__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void plain_bytes_copy_kernel(const DevPage* __restrict__ pages, const uint32_t* __restrict__ items) {
     __shared__ PbShared sh;
     const DevPage& pg = pages[items[blockIdx.x]];
     if (pg.lengths == nullptr) return;
