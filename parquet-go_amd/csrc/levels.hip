@@ -34,9 +34,6 @@ __device__ inline uint32_t equal_bytes(uint32_t x, uint32_t pattern) {
 }
 
 typedef uint64_t u64x2 __attribute__((ext_vector_type(2)));
-__device__ inline void store_pair(gptr<uint64_t> p, uint64_t a, uint64_t b) { u64x2 v = {a, b}; *(gptr<u64x2>)p = v; }
-__device__ inline void store_pair(gptr<uint32_t> p, uint32_t a, uint32_t b) { u32x2 v = {a, b}; *(gptr<u32x2>)p = v; }
-__device__ inline void store_pair(gptr<uint8_t> p, uint8_t a, uint8_t b) { *(gptr<uint16_t>)p = (uint16_t)(a | ((uint16_t)b << 8)); }
 
 // counts[w] = levels equal to `value` in stretch w.
 __global__ __launch_bounds__(LT) void levels_count_kernel(const uint8_t* __restrict__ levels_, uint64_t n, uint32_t value,
@@ -138,13 +135,31 @@ __global__ __launch_bounds__(1024) void levels_scan_kernel(uint64_t* __restrict_
     }
 }
 
-// page_optional.go:72-117 for fixed-width values.  A wavefront takes a stretch 128 slots at a
-// time, two neighbouring slots per lane: the place of a slot's value among the values is the
-// stretch's start plus the present slots before it (two ballots and mbcnt), the values are
-// read where they lie (neighbouring lanes read neighbouring values) and written 2 * W bytes
-// per lane.  Slots without a value are zero.  OFFSETS: the values are the n_values + 1
-// offsets of a byte-array page and every slot, present or not, takes the offset at its place,
-// so that null slots come out empty; dst then has n_slots + 1 entries.
+// SLOTS neighbouring elements in one store where the address allows it.
+template <typename T, uint32_t SLOTS>
+__device__ inline void store_group(gptr<T> p, const T (&v)[SLOTS], uint32_t in_bits) {
+    constexpr uint32_t ALL = (1u << SLOTS) - 1;
+    if (in_bits == ALL && ((uintptr_t)p & (SLOTS * sizeof(T) - 1)) == 0) {
+        if (sizeof(T) == 8 && SLOTS == 2) { u64x2 q = {(uint64_t)v[0], (uint64_t)v[1]}; *(gptr<u64x2>)p = q; return; }
+        if (sizeof(T) == 4 && SLOTS == 4) { u32x4 q = {(uint32_t)v[0], (uint32_t)v[1], (uint32_t)v[2], (uint32_t)v[3]}; *(gptr<u32x4>)p = q; return; }
+        if (sizeof(T) == 1 && SLOTS == 4) {
+            *(gptr<uint32_t>)p = (uint32_t)v[0] | (uint32_t)v[1] << 8 | (uint32_t)v[2] << 16 | (uint32_t)v[3] << 24;
+            return;
+        }
+    }
+#pragma unroll
+    for (uint32_t e = 0; e < SLOTS; e++)
+        if (in_bits >> e & 1) p[e] = v[e];
+}
+
+// page_optional.go:72-117 for fixed-width values.  A wavefront takes a stretch 64 * SLOTS slots
+// at a time, SLOTS neighbouring slots per lane (sixteen bytes of 8- or 4-byte values): the place
+// of a slot's value among the values is the stretch's start plus the present slots before it
+// (SLOTS ballots and mbcnt), the values are read where they lie (neighbouring lanes read
+// neighbouring values) and written in one store per lane.  Slots without a value are zero.
+// OFFSETS: the values are the n_values + 1 offsets of a byte-array page and every slot, present
+// or not, takes the offset at its place, so that null slots come out empty; dst then has
+// n_slots + 1 entries.
 template <typename T, bool OFFSETS>
 __global__ __launch_bounds__(LT) void optional_expand_kernel(const uint8_t* __restrict__ def_, uint64_t n_slots, uint32_t max_def,
                                                              const T* __restrict__ values_, uint64_t n_values, T* __restrict__ dst_,
@@ -164,47 +179,69 @@ __global__ __launch_bounds__(LT) void optional_expand_kernel(const uint8_t* __re
         info[1] = present > n_values ? PQD_ERR_UNEXPECTED_EOF : PQD_OK;
         if (OFFSETS) dst[n_slots] = values[present < n_values ? present : n_values];
     }
+    constexpr uint32_t SLOTS = sizeof(T) >= 8 ? 2 : 4, ALL = (1u << SLOTS) - 1;
+    constexpr uint32_t STEPS = STRETCH / (64 * SLOTS);
     for (uint64_t w = (uint64_t)blockIdx.x * (LT / 64) + wave; w < n_stretches; w += (uint64_t)gridDim.x * (LT / 64)) {
         uint64_t base = starts[w] >> COUNT_BITS;
         const uint64_t at = w * STRETCH;
-        constexpr uint32_t STEPS = STRETCH / 128;
-        uint32_t lv[STEPS];
+        uint32_t lv[STEPS]; // per step: which of the lane's slots hold a value (bits 0 ..), which exist (bits 8 ..)
+        // the levels of all steps first, one load per lane and step at whatever address (all of them in flight
+        // together); only the last lanes of the column read byte by byte
+        typedef uint32_t u32_a1 __attribute__((aligned(1)));
+        typedef uint16_t u16_a1 __attribute__((aligned(1)));
 #pragma unroll
         for (uint32_t u = 0; u < STEPS; u++) {
-            const uint64_t s0 = at + u * 128 + 2 * lane;
-            uint32_t a = s0 < n_slots ? def[s0] : 0xffffffffu, b = s0 + 1 < n_slots ? def[s0 + 1] : 0xffffffffu;
-            lv[u] = (a == max_def ? 1u : 0u) | (b == max_def ? 2u : 0u) | (s0 < n_slots ? 4u : 0u) | (s0 + 1 < n_slots ? 8u : 0u);
+            const uint64_t s0 = at + (uint64_t)(u * 64 + lane) * SLOTS;
+            const bool whole = s0 + SLOTS <= n_slots;
+            const uint64_t from = whole ? s0 : 0; // (a column shorter than SLOTS has no whole group: nothing is loaded then)
+            lv[u] = n_slots >= SLOTS ? (SLOTS == 2 ? (uint32_t)*(gptr<const u16_a1>)(def + from) : *(gptr<const u32_a1>)(def + from)) : 0u;
         }
 #pragma unroll
         for (uint32_t u = 0; u < STEPS; u++) {
-            const uint64_t s0 = at + u * 128 + 2 * lane;
-            const bool p0 = lv[u] & 1, p1 = lv[u] & 2, in0 = lv[u] & 4, in1 = lv[u] & 8;
-            const unsigned long long b0 = __ballot(p0), b1 = __ballot(p1);
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0)) +
-                                   __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0));
-            const uint64_t r0 = base + below, r1 = r0 + (p0 ? 1 : 0);
-            T v0 = T(), v1 = T();
-            if (OFFSETS) {
-                if (in0) v0 = values[r0 < n_values ? r0 : n_values];
-                if (in1) v1 = values[r1 < n_values ? r1 : n_values];
-            } else {
-                if (p0 && r0 < n_values) v0 = values[r0];
-                if (p1 && r1 < n_values) v1 = values[r1];
+            const uint64_t s0 = at + (uint64_t)(u * 64 + lane) * SLOTS;
+            const uint32_t d = lv[u];
+            uint32_t bits = 0;
+            if (s0 + SLOTS <= n_slots) {
+#pragma unroll
+                for (uint32_t e = 0; e < SLOTS; e++) bits |= ((d >> (8 * e)) & 0xff) == max_def ? 1u << e : 0u;
+                bits |= ALL << 8;
+            } else if (s0 < n_slots) {
+                for (uint32_t e = 0; e < SLOTS && s0 + e < n_slots; e++) bits |= (def[s0 + e] == max_def ? 1u << e : 0u) | (0x100u << e);
             }
-            if (in1 && ((uintptr_t)(dst_ + s0) & (2 * sizeof(T) - 1)) == 0) {
-                store_pair(dst + s0, v0, v1);
-            } else {
-                if (in0) dst[s0] = v0;
-                if (in1) dst[s0 + 1] = v1;
+            lv[u] = bits;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < STEPS; u++) {
+            const uint64_t s0 = at + (uint64_t)(u * 64 + lane) * SLOTS;
+            const uint32_t has = lv[u] & 0xff, in = lv[u] >> 8;
+            uint32_t below = 0, step_total = 0;
+#pragma unroll
+            for (uint32_t e = 0; e < SLOTS; e++) {
+                const unsigned long long b = __ballot(has >> e & 1);
+                below += __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0));
+                step_total += (uint32_t)__popcll(b);
             }
-            if (validity_ != nullptr) {
-                if (in1 && ((uintptr_t)(validity_ + s0) & 1) == 0) *(gptr<uint16_t>)(validity + s0) = (uint16_t)((p0 ? 1u : 0u) | (p1 ? 0x100u : 0u));
-                else {
-                    if (in0) validity[s0] = p0 ? 1 : 0;
-                    if (in1) validity[s0 + 1] = p1 ? 1 : 0;
+            uint64_t r = base + below; // the place of the lane's first value among the values
+            T v[SLOTS];
+#pragma unroll
+            for (uint32_t e = 0; e < SLOTS; e++) {
+                v[e] = T();
+                if (OFFSETS) {
+                    if (in >> e & 1) v[e] = values[r < n_values ? r : n_values];
+                } else {
+                    if ((has >> e & 1) && r < n_values) v[e] = values[r];
                 }
+                r += has >> e & 1;
             }
-            base += (uint64_t)__popcll(b0) + (uint64_t)__popcll(b1);
+            store_group<T, SLOTS>(dst + s0, v, in);
+            if (validity_ != nullptr) {
+                uint8_t ok[SLOTS];
+#pragma unroll
+                for (uint32_t e = 0; e < SLOTS; e++) ok[e] = (uint8_t)(has >> e & 1);
+                if (SLOTS == 2 && in == ALL && ((uintptr_t)(validity_ + s0) & 1) == 0) *(gptr<uint16_t>)(validity + s0) = (uint16_t)(ok[0] | ok[1] << 8);
+                else store_group<uint8_t, SLOTS>(validity + s0, ok, in);
+            }
+            base += step_total;
         }
     }
 }
