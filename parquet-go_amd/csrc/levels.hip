@@ -307,8 +307,9 @@ __global__ __launch_bounds__(LT) void row_starts_kernel(const uint8_t* __restric
         for (uint32_t u = 0; u < STRETCH / (64 * 16); u++) {
             const uint64_t s0 = w * STRETCH + (uint64_t)(u * 64 + lane) * 16;
             uint32_t mask = 0;
-            if (s0 + 16 <= n && ((uintptr_t)(rep_ + s0) & 3) == 0) {
-                const u32x4_a4 v = *(gptr<const u32x4_a4>)(rep + s0);
+            if (s0 + 16 <= n) {
+                typedef uint32_t u32x4_a1 __attribute__((ext_vector_type(4), aligned(1)));
+                const u32x4_a1 v = *(gptr<const u32x4_a1>)(rep + s0); // at whatever address the levels start
                 const uint32_t d[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) {
