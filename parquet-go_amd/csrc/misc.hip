@@ -893,7 +893,15 @@ constexpr uint32_t DCARRY = 1024;  // longest prefix length on this path
 constexpr uint32_t DIMG_SMALL = 5120, DCARRY_SMALL = 256;
 constexpr uint32_t DBAD = 0x80000000u, DBIG = 0x40000000u;
 
-__device__ inline uint32_t wave_min_u32(uint32_t v) { return wave_least_u32(v); }
+// (by ds_bpermute, not DPP: the kernels that use it are bound by issuing vector instructions, and a
+// permute goes down the LDS pipe instead)
+__device__ inline uint32_t wave_min_u32(uint32_t v) {
+    for (int d = 32; d > 0; d >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)v, d);
+        v = o < v ? o : v;
+    }
+    return v;
+}
 
 __device__ inline bool dba_parallel_candidate(const DevPage& pg, const DevResult& rp, const DevResult& rs) {
     return pg.kind == PQD_KIND_BYTE_ARRAY && pg.tile_run != nullptr && rp.status == PQD_OK && rs.status == PQD_OK &&
