@@ -1194,9 +1194,13 @@ __global__ __launch_bounds__(WT) void dba_expand_kernel(const DevPage* __restric
 #undef PQD_DBA_STEP
             const uint32_t cw = carry32[c];
             const uint32_t w = (v & m) | (cw & ~m);
-            if (rel > 0) {
-                const uint32_t n = rel < 4 ? (uint32_t)rel : 4u;
-                for (uint32_t e = 0; e < n; e++) img[q + 4 * c + e] = (uint8_t)(w >> (8 * e));
+            {
+                // the bytes of this dword below the prefix length; the others go to a spare corner of the image (four
+                // writes without a branch: four branches cost more than the writes)
+                const uint32_t n = rel <= 0 ? 0u : (rel < 4 ? (uint32_t)rel : 4u);
+                const uint32_t to = q + 4 * c, spare = IMG + 44;
+#pragma unroll
+                for (uint32_t e = 0; e < 4; e++) img[e < n ? to + e : spare] = (uint8_t)(w >> (8 * e));
             }
         }
         wave_sync();
