@@ -584,9 +584,13 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
                 if (d.num_values >= 0) {
                     // widest the values can be: the declared width, or what the dictionary's size allows
                     uint64_t width = d.bit_width > 0 ? (uint64_t)d.bit_width : 32;
-                    if (d.fused && d.dict_len > 0) {
+                    // (the indexes of a byte-array dictionary page are an item of their own, right in front of the page's)
+                    uint64_t entries = d.fused ? d.dict_len : 0;
+                    if (!d.fused && k + 1 < b->items.size() && b->items[k + 1].family == FAM_DICT_BYTES && b->items[k + 1].chain == (int32_t)k)
+                        entries = b->items[k + 1].dict_len;
+                    if (entries > 0) {
                         width = 0;
-                        for (uint64_t m = d.dict_len - 1; m; m >>= 1) width++;
+                        for (uint64_t m = entries - 1; m; m >>= 1) width++;
                     } else if (d.kind == PQD_KIND_BOOLEAN) {
                         width = 1;
                     }

@@ -584,7 +584,7 @@ __global__ __launch_bounds__(MT) void dlba_offsets_kernel(const DevPage* __restr
         }
         const uint32_t x = wave_inclusive_scan<uint32_t>(mine);
         if (lane == 63) wsum[wave] = x;
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); // LDS only: __syncthreads would wait for this turn's stores
         uint32_t before = carry, all = 0;
         for (uint32_t w = 0; w < MT / 64; w++) {
             if (w < wave) before += wsum[w];
@@ -605,10 +605,11 @@ __global__ __launch_bounds__(MT) void dlba_offsets_kernel(const DevPage* __restr
             }
         }
         carry += all;
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
         for (uint32_t e = 0; e < PER / 4; e++) cur[e] = nxt[e];
     }
+    __syncthreads();
     if (tid == 0) {
         const unsigned long long bad = first_bad;
         const uint64_t rest = pg.src_len - lr.consumed;

@@ -99,10 +99,11 @@ ONLY = os.environ.get("PQD_RATES_ONLY", "")  # run only the lines whose name con
 
 
 def run(name, pages_bytes, replicate, encoding, kind, bit_width, out_bytes_per_page, offsets_per_page, expect, steps=20,
-        dictionary=None, num_values=-1):
+        dictionary=None, num_values=-1, dictionary_offsets=None):
     if ONLY and ONLY not in name:
         return
     dict_t = torch.from_numpy(dictionary.copy()).to(DEV) if dictionary is not None else None
+    dict_off_t = torch.from_numpy(dictionary_offsets.copy()).to(DEV) if dictionary_offsets is not None else None
     uniq = len(pages_bytes)
     slot = max((len(p) + 255) // 256 * 256 for p in pages_bytes) + 256
     n_pages = uniq * replicate
@@ -124,6 +125,8 @@ def run(name, pages_bytes, replicate, encoding, kind, bit_width, out_bytes_per_p
         p.encoding, p.kind, p.bit_width = encoding, kind, bit_width
         if dict_t is not None:
             p.dict, p.dict_len = dict_t.data_ptr(), dictionary.size
+        if dict_off_t is not None:
+            p.dict_offsets, p.dict_len = dict_off_t.data_ptr(), dictionary_offsets.size - 1
         pages.append(p)
     batch = pkg.Batch(ctx, pages)
     batch.launch(stream)
@@ -177,6 +180,17 @@ def main():
     run("DELTA_LENGTH_BYTE_ARRAY urls (32 Ki)", [dlba_page(v) for v in svals], 64, E.DELTA_LENGTH_BYTE_ARRAY, K.BYTE_ARRAY, 0, nb, 32768, joined)
     run("DELTA_BYTE_ARRAY urls (32 Ki)", [dba_page(v) for v in svals], 64, E.DELTA_BYTE_ARRAY, K.BYTE_ARRAY, 0, nb, 32768, joined, steps=5)
     run("PLAIN byte arrays urls (32 Ki)", [plain_ba_page(v) for v in svals], 64, E.PLAIN, K.BYTE_ARRAY, 0, nb, 32768, joined, steps=5)
+    # the same kind of strings through a dictionary of 4096 of them: indexes of 12 bits, one bit-packed run per page
+    words = sorted(set(strings(rng, 6000)))[:4096]
+    dict_bytes = np.frombuffer(b"".join(words), np.uint8)
+    dict_offsets = np.concatenate([[0], np.cumsum([len(w) for w in words])]).astype(np.uint32)
+    idx = [rng.integers(0, 4096, size=32768) for _ in range(4)]
+    def index_page(ix):
+        bits = ((ix[:, None] >> np.arange(12)) & 1).astype(np.uint8).reshape(-1)
+        return bytes([12]) + uvarint(((ix.size // 8) << 1) | 1) + np.packbits(bits, bitorder="little").tobytes()
+    looked = [np.frombuffer(b"".join(words[int(i)] for i in ix), np.uint8) for ix in idx]
+    run("RLE_DICTIONARY strings (32 Ki)", [index_page(ix) for ix in idx], 64, E.RLE_DICTIONARY, K.BYTE_ARRAY, 0,
+        max(l.size for l in looked), 32768, looked, steps=5, dictionary=dict_bytes, dictionary_offsets=dict_offsets, num_values=32768)
     # the same strings cut into many small pages: the byte-array walkers run one wavefront per page
     small = [strings(rng, 4096) for _ in range(16)]
     sj = [np.frombuffer(b"".join(v), np.uint8) for v in small]
