@@ -183,7 +183,7 @@ __device__ inline void lookup_copy(const Lookup& L, uint64_t k0, uint8_t* img, u
     uint64_t from = 0, to = 0;
     uint32_t len = 0;
     if (in) {
-        if (ba) { from = L.doff[j]; len = L.doff[j + 1] - L.doff[j]; to = L.offsets[k]; }
+        if (ba) { const u32x2_a4 ends = *(gptr<const u32x2_a4>)(L.doff + j); from = ends.x; len = ends.y - ends.x; to = L.offsets[k]; } // (both ends in one gather)
         else { from = (uint64_t)j * L.width; len = L.width; to = k * L.width; }
     }
     const uint32_t cnt = L.n - k0 < 64 ? (uint32_t)(L.n - k0) : 64u;
