@@ -191,6 +191,17 @@ def main():
     looked = [np.frombuffer(b"".join(words[int(i)] for i in ix), np.uint8) for ix in idx]
     run("RLE_DICTIONARY strings (32 Ki)", [index_page(ix) for ix in idx], 64, E.RLE_DICTIONARY, K.BYTE_ARRAY, 0,
         max(l.size for l in looked), 32768, looked, steps=5, dictionary=dict_bytes, dictionary_offsets=dict_offsets, num_values=32768)
+    # and through a dictionary of 1024 (47 KB: it fits LDS), 10-bit indexes
+    words1k = words[::4]
+    d1k = np.frombuffer(b"".join(words1k), np.uint8)
+    o1k = np.concatenate([[0], np.cumsum([len(w) for w in words1k])]).astype(np.uint32)
+    idx1k = [rng.integers(0, 1024, size=32768) for _ in range(4)]
+    def index_page10(ix):
+        bits = ((ix[:, None] >> np.arange(10)) & 1).astype(np.uint8).reshape(-1)
+        return bytes([10]) + uvarint(((ix.size // 8) << 1) | 1) + np.packbits(bits, bitorder="little").tobytes()
+    looked1k = [np.frombuffer(b"".join(words1k[int(i)] for i in ix), np.uint8) for ix in idx1k]
+    run("RLE_DICTIONARY strings, 1 Ki entries (32 Ki)", [index_page10(ix) for ix in idx1k], 64, E.RLE_DICTIONARY, K.BYTE_ARRAY, 0,
+        max(l.size for l in looked1k), 32768, looked1k, steps=5, dictionary=d1k, dictionary_offsets=o1k, num_values=32768)
     # the same strings cut into many small pages: the byte-array walkers run one wavefront per page
     small = [strings(rng, 4096) for _ in range(16)]
     sj = [np.frombuffer(b"".join(v), np.uint8) for v in small]
