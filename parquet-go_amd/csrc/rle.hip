@@ -1288,11 +1288,11 @@ __global__ __launch_bounds__(ET) __attribute__((amdgpu_waves_per_eu(FAMILY == FA
 // expanded tile by tile by rle_page_retry_kernel, exactly what the kernel pair does, so statuses
 // and the bytes written are the same on every path.
 
-constexpr uint32_t PW_WIN = 2048;                 // bytes of the page resident at a time
+constexpr uint32_t PW_WIN = 4096;                 // bytes of the page resident at a time
 constexpr uint32_t PW_HDRS = ET;                  // headers followed per round: one per thread
 constexpr uint32_t PW_SLACK = 32;                 // LDS bytes behind the window that reads may touch
 constexpr uint64_t PAGE_RETRY = 0x5041474552455452ull; // DevResult::aux of a page rle_page_kernel left to the retry kernel
-static_assert(PW_WIN == ET * 8, "eight positions per thread");
+static_assert(PW_WIN % ET == 0, "a whole number of positions per thread");
 
 struct PageShared {
     uint32_t win[(GROUP_STAGE_PAD + PW_WIN + PW_SLACK) / 4];
@@ -1529,8 +1529,8 @@ __global__ __launch_bounds__(ET) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             const uint32_t w_lo = pos & ~15u;
             const uint32_t w_hi = w_lo + PW_WIN < end ? w_lo + PW_WIN : end;
             // ---- the window: aligned chunks that hold a byte of the page ----
-            if (tid < (PW_WIN + PW_SLACK) / 16 && w_lo + tid * 16 < end)
-                *reinterpret_cast<u32x4*>(&sh.win[(GROUP_STAGE_PAD + tid * 16) >> 2]) = *(gptr<const u32x4>)(base + w_lo + tid * 16);
+            for (uint32_t c = tid; c < (PW_WIN + PW_SLACK) / 16 && w_lo + c * 16 < end; c += ET)
+                *reinterpret_cast<u32x4*>(&sh.win[(GROUP_STAGE_PAD + c * 16) >> 2]) = *(gptr<const u32x4>)(base + w_lo + c * 16);
             // the part of a bit-packed run in progress that the window holds
             const uint32_t room = (w_hi - pos) / bw;
             const uint32_t gp = pending < room ? pending : room, pend_left = pending - gp;
