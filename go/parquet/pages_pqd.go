@@ -244,8 +244,14 @@ func (g *gpuProducer) load() (err error) {
 		return err
 	}
 	chunk := g.host.Bytes()[:size]
-	if _, err = c.file.reader.ReadAt(chunk, base); err != nil && err != io.EOF {
+	// io.EOF is what a ReaderAt may return with a full read that ends at the end of the file; fewer bytes
+	// than the footer promised would leave the buffer's tail as it was and send it off as page data
+	n, err := c.file.reader.ReadAt(chunk, base)
+	if err != nil && err != io.EOF {
 		return err
+	}
+	if n != size {
+		return fmt.Errorf("column chunk at %d: read %d of %d bytes: %w", base, n, size, io.ErrUnexpectedEOF)
 	}
 	if g.headers, err = pqd.ScanPages(chunk, meta.NumValues); err != nil {
 		return err

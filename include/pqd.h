@@ -438,7 +438,7 @@ typedef struct pqd_file_column {
     uint8_t  depth;
     uint8_t  reserved0;
     uint32_t schema_index;       /* of the leaf in FileMetaData.schema */
-    uint32_t name_offset;        /* Column.Path joined with '.', names[name_offset .. + name_len) */
+    uint32_t name_offset;        /* Column.Path, its components separated by NUL bytes (a field name may hold '.'), names[name_offset .. + name_len) */
     uint32_t name_len;
 } pqd_file_column;
 

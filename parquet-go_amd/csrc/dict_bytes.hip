@@ -47,7 +47,6 @@ __device__ inline void lds_only_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n
 
 // Runs in one workgroup of DT threads; the outcome is valid in thread 0.
 __device__ inline Outcome lookup_offsets(const Lookup& L) {
-    __shared__ uint32_t wsum[DT / 64];
     __shared__ unsigned long long first_bad;
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     Outcome o = {PQD_OK, 0, 0, 0};
@@ -102,26 +101,30 @@ __device__ inline Outcome lookup_offsets(const Lookup& L) {
                 if (k + e < L.n && (uint64_t)j[e] >= L.dict_len) { atomicMin(&first_bad, (unsigned long long)(k + e)); break; }
         }
     };
-    uint32_t carry = 0;
+    // The running sum is kept in 64 bits: a few indexes times a long dictionary entry pass 4 GiB, which
+    // offsets of 32 bits cannot name (the entries written from there on are wrapped and never used: the
+    // page ends in an error that says how many bytes it came to, and nothing is copied).
+    uint64_t carry = 0;
     uint32_t v[PER], nxt[PER];
+    __shared__ uint64_t wsum64[DT / 64];
     lengths(0, v);
     for (uint64_t base = 0; base < L.n; base += (uint64_t)DT * PER) {
         const uint64_t k = base + (uint64_t)tid * PER;
         const bool more = base + (uint64_t)DT * PER < L.n;
         if (more) lengths(base + (uint64_t)DT * PER, nxt);
         if (ba) { // uniform
-            uint32_t mine = 0;
+            uint64_t mine = 0;
 #pragma unroll
             for (uint32_t e = 0; e < PER; e++) mine += v[e];
-            const uint32_t x = wave_inclusive_scan<uint32_t>(mine);
-            if (lane == 63) wsum[wave] = x;
+            const uint64_t x = wave_inclusive_scan<uint64_t>(mine);
+            if (lane == 63) wsum64[wave] = x;
             lds_only_barrier(); // (not __syncthreads: that would wait for this turn's stores to be acknowledged)
-            uint32_t before = carry, all = 0;
+            uint64_t before = carry, all = 0;
             for (uint32_t w = 0; w < DT / 64; w++) {
-                if (w < wave) before += wsum[w];
-                all += wsum[w];
+                if (w < wave) before += wsum64[w];
+                all += wsum64[w];
             }
-            uint32_t at = before + x - mine;
+            uint32_t at = (uint32_t)(before + x - mine);
             if (k + PER <= L.n) {
 #pragma unroll
                 for (uint32_t e = 0; e < PER; e += 4) {
@@ -149,8 +152,10 @@ __device__ inline Outcome lookup_offsets(const Lookup& L) {
     if (tid == 0) {
         if (first_bad != ~0ull) { o.status = PQD_ERR_INDEX_OUT_OF_BOUNDS; o.arg = (int64_t)first_bad; }
         else if (ba) {
-            L.offsets[L.n] = carry;
-            if ((uint64_t)carry > L.dst_cap) { o.status = PQD_ERR_DST_TOO_SMALL; o.arg = (int64_t)carry; o.out_values = L.n; }
+            L.offsets[L.n] = (uint32_t)carry;
+            // more bytes than 32-bit offsets reach: no capacity makes the page decodable, the caller is told its size
+            if (carry > 0xffffffffull) { o.status = PQD_ERR_LENGTH_OUT_OF_BOUNDS; o.arg = (int64_t)carry; }
+            else if (carry > L.dst_cap) { o.status = PQD_ERR_DST_TOO_SMALL; o.arg = (int64_t)carry; o.out_values = L.n; }
             else { o.out_values = L.n; o.out_bytes = carry; }
         } else {
             o.out_values = L.n;

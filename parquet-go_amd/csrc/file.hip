@@ -99,7 +99,7 @@ void read_row_group(Compact& r, RowGroup* g) {
             int et;
             const uint64_t n = r.list(type, &et);
             if (n > 0 && et != 12) { r.ok = false; break; }
-            g->chunks.reserve(n);
+            g->chunks.reserve(n < 4096 ? n : 4096); // counts are untrusted: no allocation sized by them
             for (uint64_t i = 0; i < n && r.ok; i++) {
                 g->chunks.emplace_back();
                 read_column_chunk(r, &g->chunks.back());
@@ -145,7 +145,7 @@ struct Walk {
         }
         std::string path = parent;
         if (depth > 0) { // Column.Path leaves the root's name out (column.go:70)
-            if (!path.empty()) path += '.';
+            if (!path.empty()) path += '\0'; // a separator no field name holds: names may contain '.' (Column.Path is a []string, column.go:378-383)
             path.append((const char*)e.name, e.name_len);
         }
         if (e.has_type) {
@@ -196,9 +196,9 @@ int pqd_file_footer_range(const uint8_t* tail, uint64_t tail_len, uint64_t file_
     return PQD_OK;
 }
 
-int pqd_file_parse_footer(const uint8_t* footer, uint64_t footer_len, pqd_file_info* info, pqd_file_column* columns,
-                          uint64_t column_cap, pqd_file_row_group* row_groups, uint64_t row_group_cap, pqd_file_chunk* chunks,
-                          uint64_t chunk_cap, char* names, uint64_t names_cap, int64_t* status_arg) {
+static int parse_footer(const uint8_t* footer, uint64_t footer_len, pqd_file_info* info, pqd_file_column* columns,
+                        uint64_t column_cap, pqd_file_row_group* row_groups, uint64_t row_group_cap, pqd_file_chunk* chunks,
+                        uint64_t chunk_cap, char* names, uint64_t names_cap, int64_t* status_arg) {
     if ((footer == nullptr && footer_len > 0) || info == nullptr || (columns == nullptr && column_cap > 0) ||
         (row_groups == nullptr && row_group_cap > 0) || (chunks == nullptr && chunk_cap > 0) || (names == nullptr && names_cap > 0))
         return PQD_ERR_INVALID_ARGUMENT;
@@ -216,7 +216,7 @@ int pqd_file_parse_footer(const uint8_t* footer, uint64_t footer_len, pqd_file_i
             int et;
             const uint64_t n = r.list(type, &et);
             if (n > 0 && et != 12) { r.ok = false; break; }
-            schema.reserve(n);
+            schema.reserve(n < 4096 ? n : 4096);
             for (uint64_t i = 0; i < n && r.ok; i++) {
                 schema.emplace_back();
                 read_schema_element(r, &schema.back());
@@ -228,7 +228,7 @@ int pqd_file_parse_footer(const uint8_t* footer, uint64_t footer_len, pqd_file_i
             int et;
             const uint64_t n = r.list(type, &et);
             if (n > 0 && et != 12) { r.ok = false; break; }
-            groups.reserve(n);
+            groups.reserve(n < 4096 ? n : 4096);
             for (uint64_t i = 0; i < n && r.ok; i++) {
                 groups.emplace_back();
                 read_row_group(r, &groups.back());
@@ -272,6 +272,20 @@ int pqd_file_parse_footer(const uint8_t* footer, uint64_t footer_len, pqd_file_i
         for (uint64_t c = 0; c < walk.columns.size(); c++) chunks[g * walk.columns.size() + c] = groups[g].chunks[c];
     }
     return PQD_OK;
+}
+
+// No C++ exception may cross the C ABI (into cgo or ctypes it ends the process): a footer that makes
+// the containers run out of memory comes back as a status.
+int pqd_file_parse_footer(const uint8_t* footer, uint64_t footer_len, pqd_file_info* info, pqd_file_column* columns,
+                          uint64_t column_cap, pqd_file_row_group* row_groups, uint64_t row_group_cap, pqd_file_chunk* chunks,
+                          uint64_t chunk_cap, char* names, uint64_t names_cap, int64_t* status_arg) {
+    try {
+        return parse_footer(footer, footer_len, info, columns, column_cap, row_groups, row_group_cap, chunks, chunk_cap, names,
+                            names_cap, status_arg);
+    } catch (...) {
+        if (status_arg) *status_arg = 0;
+        return PQD_ERR_DEVICE;
+    }
 }
 
 } // extern "C"

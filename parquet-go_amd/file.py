@@ -89,7 +89,7 @@ def parse_footer(footer: bytes):
     for i in range(nc):
         c = cols[i]
         path = raw[c.name_offset:c.name_offset + c.name_len].decode("utf-8", "replace")
-        columns.append(LeafColumn(i, path.split(".") if path else [], c.kind, KIND_NAMES.get(c.kind, str(c.kind)), c.type_length,
+        columns.append(LeafColumn(i, path.split("\x00") if path else [], c.kind, KIND_NAMES.get(c.kind, str(c.kind)), c.type_length,
                                   c.repetition, c.converted_type, c.max_definition_level, c.max_repetition_level, c.depth,
                                   c.schema_index))
     row_groups = [RowGroup(rgs[g].num_rows, rgs[g].total_byte_size, rgs[g].file_offset, rgs[g].total_compressed_size)

@@ -110,6 +110,21 @@ def test_footer_of_a_file_written_here(kw):
             assert last.data_offset + last.compressed_page_size == k.total_compressed_size
 
 
+def test_field_names_that_contain_a_dot_keep_their_components():
+    """Column.Path is a []string (column.go:378-383): "a.b" inside "s" and "b" inside "s.a" are different columns."""
+    pa = pytest.importorskip("pyarrow")
+    import pyarrow.parquet as pq
+    table = pa.table({
+        "s": pa.array([{"a.b": i, "a": {"b": i + 1}} for i in range(10)]),
+        "s.a": pa.array([{"b": float(i)} for i in range(10)]),
+        "plain.dotted": pa.array(range(10), pa.int32()),
+    })
+    buf = io.BytesIO()
+    pq.write_table(table, buf, compression="NONE")
+    f = P.file.File(buf.getvalue())
+    assert [c.path for c in f.columns] == [["s", "a.b"], ["s", "a", "b"], ["s.a", "b"], ["plain.dotted"]]
+
+
 def test_damaged_footers_fail_without_harm():
     files, arrays = _load()
     rec = max(files, key=lambda r: r["footer_len"] if r["footer_len"] < 20000 else 0)

@@ -88,6 +88,41 @@ def test_byte_array_dictionary_errors_and_capacity():
     assert out.status == P.STATUS.INVALID_BIT_WIDTH
 
 
+def test_byte_array_lookup_past_4_gib_is_an_error_not_a_wrapped_size():
+    """Few indexes times one long dictionary entry come to more bytes than 32-bit offsets reach.  The
+    size has to be summed in 64 bits: wrapped, it would come back as a capacity the caller can meet,
+    and the copy would then write far past the buffer."""
+    import torch
+    P = pkg()
+    L = P.lib()
+    entry = 1 << 20
+    data = np.full(entry + 3, 0x5A, np.uint8)
+    offs = np.array([0, entry, entry + 3], np.uint32)
+    stream = C.c_void_p(torch.cuda.current_stream(0).cuda_stream)
+    d_t, o_t = torch.from_numpy(data).cuda(), torch.from_numpy(offs.view(np.int32)).cuda()
+    st = torch.zeros(3, dtype=torch.int64, device="cuda")
+    for n, want in ((5000, (P.STATUS.LENGTH_OUT_OF_BOUNDS, 5000 * entry)),      # 4.88 GiB
+                    (4097, (P.STATUS.LENGTH_OUT_OF_BOUNDS, 4097 * entry)),      # wraps to 1 MiB
+                    (3000, (P.STATUS.DST_TOO_SMALL, 3000 * entry))):            # 2.9 GiB: representable, just too large for dst
+        idx = np.zeros(n, np.int32)
+        idx[-1] = 1  # (the sum is not a multiple of the entry size)
+        want = (want[0], want[1] - entry + 3)
+        # fused with the page's index decode
+        out = decode([spec(P.ENC.RLE_DICTIONARY, P.KIND.BYTE_ARRAY, O.rle_dict_encode_int32(idx), num_values=n, dictionary=data,
+                           dictionary_offsets=offs, dst_cap=4096, offsets_cap=n + 1)], grow=False)[0]
+        assert (out.status, out.arg) == want
+        assert (out.raw == 0xA5).all(), "nothing is copied for a page that ends in an error"
+        # stand-alone, on device pointers, with a canary behind a small destination
+        i_t = torch.from_numpy(idx).cuda()
+        dst = torch.full((4096 + 4096,), 0xA5, dtype=torch.uint8, device="cuda")
+        out_offs = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
+        rc = L.pqd_dict_lookup_bytes_device(ctx().handle, P.KIND.BYTE_ARRAY, d_t.data_ptr(), o_t.data_ptr(), 2, 0, i_t.data_ptr(), n,
+                                            dst.data_ptr(), 4096, out_offs.data_ptr(), n + 1, st.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert rc == 0 and tuple(st.tolist()[:2]) == want
+        assert (dst.cpu().numpy() == 0xA5).all()
+
+
 @pytest.mark.parametrize("width", [1, 2, 3, 5, 16, 17, 100])
 def test_fixed_len_byte_array_dictionary_pages(width):
     P = pkg()

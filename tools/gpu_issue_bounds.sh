@@ -1,7 +1,8 @@
 #!/bin/bash
 # scalar- and vector-issue time of every kernel of a tool script beside its duration:
 # bash tools/gpu_issue_bounds.sh tools/misc_rates.py
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/issue; mkdir -p $O
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/issue; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 script=$R/$1; shift
 export PQD_RATES_NOCHECK=1

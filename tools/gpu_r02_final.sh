@@ -1,6 +1,7 @@
 #!/bin/bash
 # the measurement set beside the bench line: other encodings (rates + kernels), the sweeps, the wide table
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02f; mkdir -p $O
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/r02f; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 bash $R/tools/gpu_r02_misc.sh > $O/misc.log 2>&1 || { tail -20 $O/misc.log; exit 1; }
 timeout -k 10 400 python3 -u $R/tools/sweeps.py > $O/sweeps.log 2>&1 || { tail -20 $O/sweeps.log; exit 1; }

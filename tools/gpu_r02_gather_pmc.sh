@@ -2,7 +2,8 @@
 # What bounds the dictionary gather with a 512 KB dictionary: L1 <-> L2 requests and L2 hits of the
 # tile-per-workgroup kernel (gather through the caches) and of the persistent kernel (first part of
 # the dictionary in LDS), one rocprofv3 --pmc pass per counter group.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02e; mkdir -p $O
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/r02e; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 export PQD_RATES_ONLY="uniform bw16" PQD_RATES_NOCHECK=1
 for mode in 0 1; do

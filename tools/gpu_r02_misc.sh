@@ -1,6 +1,7 @@
 #!/bin/bash
 # rates of the encodings beside the headline, then the same run under rocprofv3 for the per-kernel table
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02m
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/r02m
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 timeout -k 10 200 python3 -u $R/tools/misc_rates.py > $O/rates.log 2>&1 || { tail -20 $O/rates.log; exit 1; }

@@ -1,6 +1,7 @@
 #!/bin/bash
 # kernel times (rocprofv3 --kernel-trace) of the sweep lines matching $1, dictionary-in-LDS path off and on
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02c
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/r02c
 mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 export PQD_RATES_ONLY="$1" PQD_DICT_LDS_MAX_BYTES=100000000

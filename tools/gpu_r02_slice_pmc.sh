@@ -1,7 +1,8 @@
 #!/bin/bash
 # The sliced dictionary kernel at a 512 KB dictionary (index width 16): one rocprofv3 --pmc pass per
 # counter group given on the command line (each argument one group), or a default set.
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r02s; mkdir -p $O
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out/r02s; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 export PQD_RATES_ONLY="${PQD_RATES_ONLY:-uniform bw16}" PQD_RATES_NOCHECK=1
 if [ $# -eq 0 ]; then
@@ -10,9 +11,9 @@ if [ $# -eq 0 ]; then
 fi
 for grp in "$@"; do
   tag=$(echo $grp | cut -d' ' -f1)
-  rm -rf $O/$tag
+  rm -rf "$O/$tag"
   timeout -s KILL 90 rocprofv3 --pmc $grp -d $O/$tag -o c -- python3 $R/tools/sweeps.py dictionary > $O/$tag.log 2>&1 || { tail -3 $O/$tag.log; exit 1; }
   echo "== $grp"
   python3 $R/tools/pmc_summary.py $(find $O/$tag -name "*counter_collection.csv" -o -name "*_results.db" | head -1) rle_
 done
-rm -rf $O
+rm -rf "$O"

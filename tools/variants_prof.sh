@@ -1,7 +1,8 @@
 #!/bin/bash
 # On the GPU box: kernel times of the lines matching $1 of a rates tool ($2..., default tools/misc_rates.py)
 # for each library variant in build_exp/
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
+set -u
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}; O=$R/gpurun_out
 cd /tmp; export TMPDIR=/tmp
 export PQD_RATES_ONLY="$1" PQD_RATES_NOCHECK=1
 shift
