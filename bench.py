@@ -224,46 +224,82 @@ def time_steps(S, torch, wl, stream, steps, warmup, dist=None):
     return wall, kernel_ms
 
 
-def cpu_baseline(wl, budget_s=6.0):
-    """The CPU restatement of the reference decoder (oracle/, kind "port") on a bounded sample of
-    the same pages: on one host core, and on the box's share of host cores with one page per task
-    (a thread per core; the C decoder runs outside the interpreter lock)."""
+def cpu_baseline(wl, c1, budget_s=3.0):
+    """CPU decoders of oracle/ on a bounded sample of the same pages, on one host core and on the box's
+    share of host cores (a page per task, a thread per core; the C decoders run outside the interpreter
+    lock).  Two ports are timed: "port-opt" (oracle/pq_port_opt.c: width-specialised word-at-a-time
+    unpack, scalar running sum, organised like the reference's amd64 kernels) is the baseline reported;
+    "port" (oracle/pq_oracle.c, the bit-by-bit restatement the parity tests check against) stands beside it."""
     import threading
     from oracle import pqoracle as O
     L = O.lib()
-    pages = wl.enc_pages[: min(len(wl.enc_pages), 16)]
-    srcs = [np.frombuffer(p, np.uint8) for p in pages]
+    cores = max(1, min(16, os.cpu_count() or 1))  # a one-GPU box is given 16 host cores
 
-    def worker(k, n_threads, deadline, out):
-        dst = np.zeros(wl.values_per_page, np.int64)
-        done = 0
-        while time.perf_counter() < deadline:
-            for j in range(k, len(srcs), n_threads) if n_threads <= len(srcs) else (k % len(srcs),):
-                s = srcs[j]
-                r = L.pqo_delta_decode_int64(dst.ctypes.data, dst.nbytes, s.ctypes.data, s.size)
-                assert r.status == 0
-                done += dst.nbytes
-        out[k] = done
-
-    def run(n_threads):
+    def run(n_threads, n_pages, one_page):
+        """one_page(j, scratch) decodes page j and returns the bytes it produced."""
         out = [0] * n_threads
         t0 = time.perf_counter()
-        ts = [threading.Thread(target=worker, args=(k, n_threads, t0 + budget_s, out)) for k in range(n_threads)]
+
+        def worker(k):
+            scratch = {}
+            done = 0
+            while time.perf_counter() < t0 + budget_s:
+                for j in (range(k, n_pages, n_threads) if n_threads <= n_pages else (k % n_pages,)):
+                    done += one_page(j, scratch)
+            out[k] = done
+
+        ts = [threading.Thread(target=worker, args=(k,)) for k in range(n_threads)]
         for t in ts:
             t.start()
         for t in ts:
             t.join()
         return sum(out) / (time.perf_counter() - t0) / 1e9
 
-    one = run(1)
-    cores = max(1, min(16, os.cpu_count() or 1))  # a one-GPU box is given 16 host cores
-    many = run(cores) if cores > 1 else one
-    return {"value": round(many, 3), "unit": "GB/s", "cores": cores, "kind": "port", "one_core": round(one, 3),
-            "sample": f"{len(srcs)} of the workload's pages ({wl.values_per_page} values each), decoded over and over for "
-                      f"{budget_s:.0f} s by oracle/pq_oracle.c (scalar restatement of encoding/delta/binary_packed.go): "
-                      f"on one host core, then on {cores} threads with a page per task.  The port unpacks bit by bit and is not the "
-                      f"reference's speed: parquet-go's amd64 kernels decode this family at about 6 GB/s per core "
-                      f"(docs/delta-byte-array-prefix.md:235-238 of the reference); Go is not installed here, so that was not run"}
+    srcs = [np.frombuffer(p, np.uint8) for p in wl.enc_pages[: min(len(wl.enc_pages), 16)]]
+
+    def delta_with(fn):
+        def one(j, scratch):
+            dst = scratch.setdefault("dst", np.zeros(wl.values_per_page, np.int64))
+            r = fn(dst.ctypes.data, dst.nbytes, srcs[j].ctypes.data, srcs[j].size)
+            assert r.status == 0
+            return dst.nbytes
+        return one
+
+    dsrcs = [np.frombuffer(p, np.uint8) for p in c1.enc_pages[: min(len(c1.enc_pages), 16)]]
+    dictionary = np.ascontiguousarray(c1.dictionary)
+
+    def dict_opt(j, scratch):
+        dst = scratch.setdefault("dst", np.zeros(c1.values_per_page, np.int64))
+        r = L.pqopt_rle_dict_lookup_int64(dst.ctypes.data, c1.values_per_page, dsrcs[j].ctypes.data, dsrcs[j].size, dictionary.ctypes.data, dictionary.size)
+        assert r.status == 0
+        return dst.nbytes
+
+    def dict_port(j, scratch):
+        dst = scratch.setdefault("dst", np.zeros(c1.values_per_page, np.int64))
+        idx = scratch.setdefault("idx", np.zeros(c1.values_per_page, np.int32))
+        r = L.pqo_rle_dict_decode_int32(idx.ctypes.data, idx.nbytes, dsrcs[j].ctypes.data, dsrcs[j].size)
+        r2 = L.pqo_dict_lookup(dst.ctypes.data, 8, dictionary.ctypes.data, dictionary.size, 8, idx.ctypes.data, c1.values_per_page)
+        assert r.status == 0 and r2.status == 0
+        return dst.nbytes
+
+    def both(n_pages, one_page):
+        one = run(1, n_pages, one_page)
+        return round(one, 3), round(run(cores, n_pages, one_page) if cores > 1 else one, 3)
+
+    opt_one, opt_many = both(len(srcs), delta_with(L.pqopt_delta_decode_int64))
+    port_one, port_many = both(len(srcs), delta_with(L.pqo_delta_decode_int64))
+    dopt_one, dopt_many = both(len(dsrcs), dict_opt)
+    dport_one, dport_many = both(len(dsrcs), dict_port)
+    return {"value": opt_many, "unit": "GB/s", "cores": cores, "kind": "port-opt", "one_core": opt_one,
+            "port": {"value": port_many, "one_core": port_one, "kind": "port"},
+            "rle_dictionary_int64": {"value": dopt_many, "one_core": dopt_one, "kind": "port-opt", "port": {"value": dport_many, "one_core": dport_one, "kind": "port"}},
+            "sample": f"DELTA_BINARY_PACKED int64 (the figure in `value`): {len(srcs)} of the workload's pages ({wl.values_per_page} values each) decoded over "
+                      f"and over for {budget_s:.0f} s per leg, on one host core and then on {cores} threads with a page per task, decoded GB/s; "
+                      f"rle_dictionary_int64: the same with {len(dsrcs)} of the RLE_DICTIONARY pages ({c1.values_per_page} values each, indexes decoded "
+                      f"and looked up in the 64 Ki-entry dictionary).  port-opt = oracle/pq_port_opt.c, a tuned C port (unpackers specialised per "
+                      f"width, a miniblock of 32 values per call, scalar running sum, -O3 -march=x86-64-v3); port = oracle/pq_oracle.c, the "
+                      f"bit-by-bit restatement the parity tests use.  The reference itself is Go and is not installed here; its amd64 kernels "
+                      f"decode this family at about 6 GB/s per core (docs/delta-byte-array-prefix.md:235-238 of the reference)"}
 
 
 def _timed_pair(S, torch, first, second, stream, steps, warmup, dist):
@@ -449,7 +485,7 @@ def run_headline(args, pkg, S, torch, ctx, device, stream, rank, world, dist, re
                                            "launched_by_itself_cold": _alone(c1, ms_dict_cold, "each launch behind 2 GB of stores to another buffer and 2 ms of idle device")}},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result["cpu_baseline"] = cpu_baseline(wl)
+        result["cpu_baseline"] = cpu_baseline(wl, c1)
     else:
         result["cpu_baseline"] = None
     return result

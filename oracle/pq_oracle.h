@@ -77,6 +77,12 @@ uint64_t pqo_plain_encode_byte_array(uint8_t* dst, uint64_t cap, const uint8_t* 
 
 int pqo_selftest_unpack(void);
 
+/* ---- tuned ports of the benchmark's two decoders (pq_port_opt.c; cpu_baseline "port-opt") ---- */
+pqo_result pqopt_delta_decode_int64(int64_t* dst, uint64_t cap_bytes, const uint8_t* src, uint64_t n);
+/* values of an RLE_DICTIONARY int64 page: indexes decoded, fixed up to num_values, looked up (dst holds num_values) */
+pqo_result pqopt_rle_dict_lookup_int64(int64_t* dst, uint64_t num_values, const uint8_t* src, uint64_t n, const int64_t* dict,
+                                       uint64_t dict_len);
+
 /* mixed-run level stream in parquet-mr style (arbitrary run lengths) */
 uint64_t pqo_rle_encode_levels_mr(uint8_t* dst, uint64_t cap, const uint8_t* src, uint64_t n, uint32_t bit_width);
 

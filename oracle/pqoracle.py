@@ -37,8 +37,8 @@ class Result:
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "pq_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("pq_oracle.c", "pq_port_opt.c", "pq_oracle.h")]
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(_SO) < os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "libpqoracle.so"], stdout=subprocess.DEVNULL)
     return _SO
 
@@ -71,6 +71,8 @@ def lib():
             "pqo_dlba_estimate": (i64, [vp, u64]),
             "pqo_dba_estimate": (i64, [vp, u64]),
             "pqo_dict_lookup": (_Res, [vp, u64, vp, u64, u32, vp, u64]),
+            "pqopt_delta_decode_int64": (_Res, [vp, u64, vp, u64]),
+            "pqopt_rle_dict_lookup_int64": (_Res, [vp, u64, vp, u64, vp, u64]),
             "pqo_indexed_page_fixup": (None, [vp, u64, u64]),
             "pqo_rle_encode_levels": (u64, [vp, u64, vp, u64, u32]),
             "pqo_rle_encode_int32": (u64, [vp, u64, vp, u64, u32]),
@@ -230,6 +232,22 @@ def dict_lookup(dictionary: np.ndarray, indexes: np.ndarray, row_stride: int = 0
     rows = np.zeros(max(1, idx.size * stride), dtype=np.uint8)
     res = lib().pqo_dict_lookup(_p(rows), stride, _p(d), d.size, width, _p(idx), idx.size)
     return _mk(res, rows[: idx.size * stride])
+
+
+def opt_delta_decode_int64(src, cap: int = 0) -> Result:
+    """The tuned port (pq_port_opt.c) of delta_decode_int64: same results, for the benchmark's CPU leg."""
+    s = _src(src)
+    res, v = _retry(lambda d, c: lib().pqopt_delta_decode_int64(_p(d), c, _p(s), s.size), np.int64, cap or 64)
+    return _mk(res, v)
+
+
+def opt_rle_dict_lookup_int64(src, num_values: int, dictionary: np.ndarray) -> Result:
+    """The tuned port of rle_dict_decode_int32 + indexed_page_fixup + dict_lookup for an int64 dictionary."""
+    s = _src(src)
+    d = np.ascontiguousarray(dictionary, dtype=np.int64)
+    dst = np.zeros(max(1, num_values), np.int64)
+    res = lib().pqopt_rle_dict_lookup_int64(_p(dst), num_values, _p(s), s.size, _p(d), d.size)
+    return _mk(res, dst[:num_values] if res.status == 0 else dst[:0])
 
 
 def indexed_page_fixup(values: np.ndarray, num_values: int) -> np.ndarray:
