@@ -142,3 +142,35 @@ func encodeValues(e encoding.Encoding, ctx *Context, kind, width int, dst []byte
 		return dst[:outBytes], goError(e, st, int64(statusArg))
 	}
 }
+
+// encodeByteArray renders EncodeByteArray(dst, src, offsets) (encoding/encoding.go:38-40) for the
+// PLAIN, DELTA_LENGTH_BYTE_ARRAY and DELTA_BYTE_ARRAY codecs: value k is src[offsets[k]:offsets[k+1]].
+// With kind FIXED_LEN_BYTE_ARRAY and no offsets it is ByteArrayEncoding.EncodeFixedLenByteArray
+// (encoding/delta/byte_array.go:76-122): n values of `size` bytes.
+func encodeByteArray(e encoding.Encoding, ctx *Context, kind, size int, dst []byte, src []byte, offsets []uint32, n int) ([]byte, error) {
+	dst = dst[:cap(dst)]
+	if bound := int(C.pqd_encode_bound_byte_array(C.int(e.Encoding()), C.uint64_t(n), C.uint64_t(len(src)))); len(dst) < bound {
+		dst = make([]byte, bound)
+	}
+	for attempt := 0; ; attempt++ {
+		var outBytes C.uint64_t
+		var statusArg C.int64_t
+		st := C.pqd_encode_byte_array(ctx.handle(), C.int(e.Encoding()), C.int(kind), C.int(size),
+			unsafe.Pointer(unsafe.SliceData(src)), C.uint64_t(len(src)),
+			(*C.uint32_t)(unsafe.Pointer(unsafe.SliceData(offsets))), C.uint64_t(n),
+			(*C.uint8_t)(unsafe.Pointer(unsafe.SliceData(dst))), C.uint64_t(len(dst)), &outBytes, &statusArg)
+		if st == C.PQD_ERR_DST_TOO_SMALL && attempt < 3 && int64(statusArg) > int64(len(dst)) {
+			dst = make([]byte, int64(statusArg))
+			continue
+		}
+		return dst[:outBytes], goError(e, st, int64(statusArg))
+	}
+}
+
+// valueCount is the number of values n + 1 offsets stand for (none for no offsets at all).
+func valueCount(offsets []uint32) int {
+	if len(offsets) == 0 {
+		return 0
+	}
+	return len(offsets) - 1
+}

@@ -64,6 +64,11 @@ func (e *Plain) EstimateDecodeByteArraySize(src []byte) int {
 
 func (e *Plain) CanDecodeInPlace() bool { return canDecodeInPlace(e) }
 
+// EncodeByteArray writes every value behind its 4-byte length (encoding/plain/plain.go:44-57).
+func (e *Plain) EncodeByteArray(dst []byte, src []byte, offsets []uint32) ([]byte, error) {
+	return encodeByteArray(e, e.Context, kindByteArray, 0, dst, src, offsets, valueCount(offsets))
+}
+
 // PlainDictionary stands in for plain.DictionaryEncoding (encoding/plain/dictionary.go:9-27):
 // DecodeInt32 is a PLAIN decode of raw int32 values.  Data pages marked PLAIN_DICTIONARY are
 // decoded with RLEDictionary; that rewrite is the caller's (column.go:850-857).
@@ -100,6 +105,20 @@ func (e *RLE) DecodeBoolean(dst []byte, src []byte) ([]byte, error) {
 
 func (e *RLE) DecodeInt32(dst []int32, src []byte) ([]int32, error) {
 	return decodeFixed(e, e.Context, kindInt32, e.BitWidth, dst, src)
+}
+
+// EncodeLevels, EncodeBoolean and EncodeInt32 (encoding/rle/rle.go:43-61): encodeBytes, the 4-byte
+// length and encodeBits, encodeInt32, each with the codec's BitWidth.
+func (e *RLE) EncodeLevels(dst []byte, src []uint8) ([]byte, error) {
+	return encodeValues(e, e.Context, kindLevels, e.BitWidth, dst, unsafe.Pointer(unsafe.SliceData(src)), len(src))
+}
+
+func (e *RLE) EncodeBoolean(dst []byte, src []byte) ([]byte, error) {
+	return encodeValues(e, e.Context, kindBoolean, 0, dst, unsafe.Pointer(unsafe.SliceData(src)), len(src))
+}
+
+func (e *RLE) EncodeInt32(dst []byte, src []int32) ([]byte, error) {
+	return encodeValues(e, e.Context, kindInt32, e.BitWidth, dst, unsafe.Pointer(unsafe.SliceData(src)), len(src))
 }
 
 // RLEDictionary stands in for rle.DictionaryEncoding (encoding/rle/dictionary.go:11-59): the
@@ -183,6 +202,12 @@ func (e *DeltaLengthByteArray) EstimateDecodeByteArraySize(src []byte) int {
 
 func (e *DeltaLengthByteArray) CanDecodeInPlace() bool { return canDecodeInPlace(e) }
 
+// EncodeByteArray writes the lengths as DELTA_BINARY_PACKED int32 and then all of src
+// (encoding/delta/length_byte_array.go:20-35).
+func (e *DeltaLengthByteArray) EncodeByteArray(dst []byte, src []byte, offsets []uint32) ([]byte, error) {
+	return encodeByteArray(e, e.Context, kindByteArray, 0, dst, src, offsets, valueCount(offsets))
+}
+
 // DeltaByteArray stands in for delta.ByteArrayEncoding (encoding/delta/byte_array.go:14-183).
 type DeltaByteArray struct {
 	encoding.NotSupported
@@ -194,6 +219,22 @@ func (e *DeltaByteArray) Encoding() format.Encoding { return format.DeltaByteArr
 
 func (e *DeltaByteArray) DecodeByteArray(dst []byte, src []byte, offsets []uint32) ([]byte, []uint32, error) {
 	return decodeByteArray(e, e.Context, dst, src, offsets)
+}
+
+// EncodeByteArray and EncodeFixedLenByteArray write prefix lengths, suffix lengths and suffixes
+// (encoding/delta/byte_array.go:26-122).
+func (e *DeltaByteArray) EncodeByteArray(dst []byte, src []byte, offsets []uint32) ([]byte, error) {
+	return encodeByteArray(e, e.Context, kindByteArray, 0, dst, src, offsets, valueCount(offsets))
+}
+
+func (e *DeltaByteArray) EncodeFixedLenByteArray(dst []byte, src []byte, size int) ([]byte, error) {
+	if size < 0 || size > encoding.MaxFixedLenByteArraySize {
+		return dst[:0], encoding.Error(e, encoding.ErrInvalidArgument)
+	}
+	if size == 0 || len(src)%size != 0 {
+		return dst[:0], encoding.ErrEncodeInvalidInputSize(e, "FIXED_LEN_BYTE_ARRAY", len(src))
+	}
+	return encodeByteArray(e, e.Context, kindFixedLenByteArray, size, dst, src, nil, len(src)/size)
 }
 
 func (e *DeltaByteArray) DecodeFixedLenByteArray(dst []byte, src []byte, size int) ([]byte, error) {

@@ -213,7 +213,17 @@ int pqd_dict_lookup_bytes_device(pqd_ctx* ctx, int32_t kind, const void* dict_de
  *     dictionary indexes (rle.DictionaryEncoding.EncodeInt32, encoding/rle/dictionary.go:23-28, 52-59,
  *     encoding/rle/rle.go:203-249);
  *   PQD_ENC_BYTE_STREAM_SPLIT, kind INT32 / INT64 / FLOAT / DOUBLE / FIXED_LEN_BYTE_ARRAY
- *     (encoding/bytestreamsplit/bytestreamsplit.go:19-33, bytestreamsplit_amd64.s:56-208).
+ *     (encoding/bytestreamsplit/bytestreamsplit.go:19-33, bytestreamsplit_amd64.s:56-208);
+ *   PQD_ENC_RLE with bit_width: kind LEVELS, n_values bytes of levels (rle.Encoding.EncodeLevels, encodeBytes,
+ *     encoding/rle/rle.go:43-46, 141-201); kind BOOLEAN, n_values BYTES of packed bits, the 4-byte length
+ *     in front (EncodeBoolean, encodeBits, rle.go:48-56, 97-139); kind INT32 (EncodeInt32, rle.go:58-61, 203-249);
+ *     a width the encoder refuses (above 8 / 32, or 0 with a value that is not 0): PQD_ERR_INVALID_BIT_WIDTH;
+ *   PQD_ENC_PLAIN, kind BYTE_ARRAY: every value behind its 4-byte length (plain.Encoding.EncodeByteArray,
+ *     encoding/plain/plain.go:44-57);
+ *   PQD_ENC_DELTA_LENGTH_BYTE_ARRAY, kind BYTE_ARRAY: the lengths as DELTA_BINARY_PACKED int32, then all of
+ *     src (delta.LengthByteArrayEncoding.EncodeByteArray, encoding/delta/length_byte_array.go:20-35);
+ *   PQD_ENC_DELTA_BYTE_ARRAY, kind BYTE_ARRAY / FIXED_LEN_BYTE_ARRAY: prefix lengths, suffix lengths, suffixes
+ *     (delta.ByteArrayEncoding.EncodeByteArray / EncodeFixedLenByteArray, encoding/delta/byte_array.go:26-122).
  * Other combinations answer PQD_ERR_NOT_SUPPORTED, as encoding.NotSupported does.
  * All pointers are device pointers; `src` is aligned to the value width (4 or 8 bytes) except
  * for BYTE_STREAM_SPLIT, `dst` may have any alignment.  PQD_ERR_DST_TOO_SMALL: status_arg = bytes
@@ -231,10 +241,18 @@ typedef struct pqd_encode_page {
     int32_t     status;
     int64_t     status_arg;
     uint64_t    out_bytes;
+    /* BYTE_ARRAY pages: value k is src[offsets[k] .. offsets[k + 1]) (n_values + 1 device offsets, as
+     * encoding.Values holds them, encoding/values.go:47-52) and src holds src_bytes bytes;
+     * FIXED_LEN_BYTE_ARRAY through DELTA_BYTE_ARRAY: offsets is NULL, src_bytes = n_values * bit_width */
+    const uint32_t* offsets;
+    uint64_t    src_bytes;
 } pqd_encode_page;
 
-/* The largest page `n_values` values can encode to (0: not supported). */
+/* The largest page `n_values` values can encode to (0: not supported, or a byte-array page). */
 uint64_t pqd_encode_bound(int encoding, int kind, int bit_width, uint64_t n_values);
+/* The same for BYTE_ARRAY / FIXED_LEN_BYTE_ARRAY pages of `src_bytes` bytes of values in all
+ * (PLAIN, DELTA_LENGTH_BYTE_ARRAY, DELTA_BYTE_ARRAY). */
+uint64_t pqd_encode_bound_byte_array(int encoding, uint64_t n_values, uint64_t src_bytes);
 
 /* Bytes of device scratch pqd_encode_batch needs for these pages (src, dst are not looked at). */
 uint64_t pqd_encode_workspace_size(const pqd_encode_page* pages, uint64_t n_pages);
@@ -248,6 +266,24 @@ int pqd_encode_batch(pqd_ctx* ctx, pqd_encode_page* pages, uint64_t n_pages, voi
  * and `kind` name.  Go's "may grow dst" is PQD_ERR_DST_TOO_SMALL with the size in *status_arg. */
 int pqd_encode_values(pqd_ctx* ctx, int encoding, int kind, int bit_width, const void* src, uint64_t n_values,
                       uint8_t* dst, uint64_t dst_cap, uint64_t* out_bytes, int64_t* status_arg);
+
+/* One BYTE_ARRAY page, host pointers in and out: EncodeByteArray(dst, src, offsets) of plain.Encoding,
+ * delta.LengthByteArrayEncoding and delta.ByteArrayEncoding (encoding/plain/plain.go:44-57,
+ * encoding/delta/length_byte_array.go:20-35, encoding/delta/byte_array.go:26-74); `offsets` holds
+ * n_values + 1 entries, or is NULL for no values at all.  With kind FIXED_LEN_BYTE_ARRAY, type_length and
+ * offsets NULL: ByteArrayEncoding.EncodeFixedLenByteArray (byte_array.go:76-122). */
+int pqd_encode_byte_array(pqd_ctx* ctx, int encoding, int kind, int type_length, const void* src, uint64_t src_bytes,
+                          const uint32_t* offsets, uint64_t n_values, uint8_t* dst, uint64_t dst_cap, uint64_t* out_bytes,
+                          int64_t* status_arg);
+
+/* The smallest and the largest value of a page, its min / max statistics: boundsInt32 / Int64 / Uint32 /
+ * Uint64 / Float32 / Float64 (page_bounds_purego.go:9-107, page_bounds_amd64.s; the typed pages' Bounds,
+ * page_int32.go / page_int64.go / ...), with the loop's comparisons: of values that compare equal the first
+ * stays, a NaN is only ever the answer when it is the first value.  Arguments as pqd_dict_bounds_device
+ * without the dictionary: values_dev holds n values of `kind` (INT32, INT64, FLOAT, DOUBLE; is_unsigned for
+ * the uint32 / uint64 pages), bounds_dev gets {min, max} (zeros when n = 0), status_dev {PQD_OK, 0}. */
+int pqd_page_bounds_device(pqd_ctx* ctx, int32_t kind, int32_t is_unsigned, const void* values_dev, uint64_t n, void* bounds_dev,
+                           void* workspace_dev, uint64_t workspace_bytes, int64_t* status_dev, void* hip_stream);
 
 /* Dictionary.Bounds (dictionary.go:71-72): the smallest and the largest of dict[indexes[i]], the
  * min / max statistics of a dictionary-encoded page (dictionaryBoundsInt32 / Int64 / Float32 /

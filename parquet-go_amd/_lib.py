@@ -85,6 +85,7 @@ class EncodePage(C.Structure):
         ("src", C.c_void_p), ("n_values", C.c_uint64), ("dst", C.c_void_p), ("dst_cap", C.c_uint64),
         ("encoding", C.c_int32), ("kind", C.c_int32), ("bit_width", C.c_int32), ("status", C.c_int32),
         ("status_arg", C.c_int64), ("out_bytes", C.c_uint64),
+        ("offsets", C.c_void_p), ("src_bytes", C.c_uint64),
     ]
 
 
@@ -166,10 +167,13 @@ SYMBOLS = {
     "pqd_dict_lookup_device": (_int, [_vp, _vp, _u64, C.c_uint32, _vp, _u64, _vp, _u64, _vp, _vp]),
     "pqd_dict_lookup_bytes_device": (_int, [_vp, C.c_int32, _vp, _vp, _u64, C.c_uint32, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp]),
     "pqd_encode_bound": (_u64, [_int, _int, _int, _u64]),
+    "pqd_encode_bound_byte_array": (_u64, [_int, _u64, _u64]),
+    "pqd_encode_byte_array": (_int, [_vp, _int, _int, _int, _vp, _u64, _vp, _u64, _vp, _u64, _pu64, _pi64]),
     "pqd_encode_workspace_size": (_u64, [C.POINTER(EncodePage), _u64]),
     "pqd_encode_batch": (_int, [_vp, C.POINTER(EncodePage), _u64, _vp, _u64, _vp]),
     "pqd_encode_values": (_int, [_vp, _int, _int, _int, _vp, _u64, _vp, _u64, _pu64, _pi64]),
     "pqd_dict_bounds_device": (_int, [_vp, C.c_int32, C.c_int32, _vp, _u64, _vp, _u64, _vp, _vp, _u64, _vp, _vp]),
+    "pqd_page_bounds_device": (_int, [_vp, C.c_int32, C.c_int32, _vp, _u64, _vp, _vp, _u64, _vp, _vp]),
     "pqd_levels_workspace_size": (_u64, [_u64]),
     "pqd_levels_count_equal_device": (_int, [_vp, _vp, _u64, C.c_uint8, _vp, _u64, _vp, _vp]),
     "pqd_optional_expand_device": (_int, [_vp, _vp, _u64, C.c_uint8, _vp, _u64, C.c_uint32, C.c_int32, _vp, _vp, _vp, _u64, _vp, _vp]),

@@ -31,6 +31,9 @@ namespace pqd {
 namespace {
 
 constexpr int ET = 256;              // threads per workgroup
+typedef uint64_t u64_a1e __attribute__((aligned(1)));
+typedef uint32_t u32_a1e __attribute__((aligned(1)));
+typedef uint32_t u32x4_a1e __attribute__((ext_vector_type(4), aligned(1)));
 constexpr uint32_t DE_BLOCK = 128;   // values per block (binary_packed.go:18-22)
 constexpr uint32_t DE_MINI = 32;     // values per miniblock
 constexpr uint32_t DE_TILE_BLOCKS = 16; // blocks per workgroup
@@ -56,9 +59,20 @@ struct EncPage {
     uint32_t* first_start; // per tile: first group of the tile that starts a run, or ~0
     uint32_t* next_start;  // per tile: first run start after the tile
     uint32_t* or_word;     // OR of all indexes of the page
+    // RLE levels scratch (first_start / next_start / or_word as above)
+    uint32_t* first_start_b; // per tile: first run start if the tile is entered inside a bit-packed run (first_start: inside repeats)
+    uint8_t* tile_fn;        // per tile: what the tile does to the run state (LV_B, LV_R, LV_I), then the state it is entered in
+    uint32_t fixed_bw;       // RLE with the width given (levels, RLE int32): the width; RLE_DICTIONARY: ~0
+    // byte arrays
+    const uint32_t* offsets; // n_values + 1 offsets into src; null: FIXED_LEN values of `width` bytes (or no values at all)
+    uint64_t src_len;        // bytes at src
+    int32_t* len_a;          // scratch, n_values: DELTA_LENGTH lengths / DELTA_BYTE_ARRAY prefix lengths
+    int32_t* len_b;          // scratch, n_values: DELTA_BYTE_ARRAY suffix lengths, then where each suffix starts in the output
+    uint32_t chain_a, chain_b; // the internal DELTA int32 items that encode len_a / len_b (positions in the page array)
 };
 
-enum EncFamily : int32_t { EF_NONE = 0, EF_DELTA32 = 1, EF_DELTA64 = 2, EF_RLE_DICT = 3, EF_BSS = 4, EF_N = 5 };
+enum EncFamily : int32_t { EF_NONE = 0, EF_DELTA32 = 1, EF_DELTA64 = 2, EF_RLE_DICT = 3, EF_BSS = 4, EF_DELTA32_B = 5, EF_LEVELS = 6, EF_BOOL = 7,
+                           EF_PLAIN_BA = 8, EF_DLBA = 9, EF_DBA = 10, EF_N = 11 };
 
 constexpr uint64_t ST_AGGREGATE = 1ull << 62, ST_INCLUSIVE = 2ull << 62, ST_FLAGS = 3ull << 62;
 
@@ -506,9 +520,14 @@ __global__ __launch_bounds__(ET) void rle_encode_write_kernel(EncPage* __restric
     const uint64_t n = pg.n_values, groups = n / 8;
     const uint64_t g = tile * RE_GROUPS + threadIdx.x;
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t bw = bits_len64(*pg.or_word);  // rle/dictionary.go:52-59: the widest index
+    const bool dict_form = pg.fixed_bw == 0xffffffffu;
+    const uint32_t bw = dict_form ? bits_len64(*pg.or_word) : pg.fixed_bw;  // rle/dictionary.go:52-59: the widest index
     const uint32_t vb = (bw + 7) / 8;
     const bool last_tile = tile + 1 == pg.n_tiles;
+    if (!dict_form && bw == 0 && *pg.or_word != 0) { // rle.go:207-212: width 0 takes nothing but zeros
+        if (last_tile && threadIdx.x == 0) { pg.status = PQD_ERR_INVALID_BIT_WIDTH; pg.arg = 0; pg.out_bytes = 0; }
+        return;
+    }
 
     Group cur;
     bool have = g < groups && bw > 0, start = false;
@@ -553,7 +572,8 @@ __global__ __launch_bounds__(ET) void rle_encode_write_kernel(EncPage* __restric
     }
     // the head of the page: the width byte; a page of zeros is one header and no value (rle.go:204-207)
     uint32_t head = 0;
-    if (tile == 0) head = 1 + (bw == 0 ? uvarint_len(n << 1) : 0);
+    const uint32_t wb = dict_form ? 1u : 0u; // the dictionary form starts with its width byte
+    if (tile == 0) head = wb + (bw == 0 ? uvarint_len(n << 1) : 0);
     uint32_t tail_bytes = 0;
     if (last_tile && bw > 0) {
         for (uint64_t i = groups * 8; i < n;) {
@@ -569,17 +589,19 @@ __global__ __launch_bounds__(ET) void rle_encode_write_kernel(EncPage* __restric
         if (lane == 0) sh.before = before;
     }
     if (tile == 0 && threadIdx.x == 0) {
-        stage_or(sh.stage, 0, bw, 8);
-        if (bw == 0) stage_uvarint(sh.stage, 1, n << 1);
+        if (dict_form) stage_or(sh.stage, 0, bw, 8);
+        if (bw == 0) stage_uvarint(sh.stage, wb, n << 1);
     }
     if (have) {
         uint32_t o = head + off;
         if (start) o += stage_uvarint(sh.stage, o, cur.same ? (8 * run_groups) << 1 : (run_groups << 1) | 1);
+        // (with the width given, a value may be wider: packed fields keep its low bits, a repeated value its low bytes)
+        const uint32_t fmask = bw >= 32 ? 0xffffffffu : (1u << bw) - 1, vmask = vb >= 4 ? 0xffffffffu : (1u << (8 * vb)) - 1;
         if (cur.same) {
-            if (start) stage_or(sh.stage, 8ull * o, cur.v[0], 8 * vb);
+            if (start) stage_or(sh.stage, 8ull * o, cur.v[0] & vmask, 8 * vb);
         } else {
 #pragma unroll
-            for (uint32_t e = 0; e < 8; e++) stage_or(sh.stage, 8ull * o + (uint64_t)e * bw, cur.v[e], bw);
+            for (uint32_t e = 0; e < 8; e++) stage_or(sh.stage, 8ull * o + (uint64_t)e * bw, cur.v[e] & fmask, bw);
         }
     }
     if (last_tile && bw > 0 && threadIdx.x == 0) {
@@ -588,7 +610,7 @@ __global__ __launch_bounds__(ET) void rle_encode_write_kernel(EncPage* __restric
             uint64_t j = i + 1;
             while (j < n && src[j] == src[i]) j++;
             o += stage_uvarint(sh.stage, o, (j - i) << 1);
-            stage_or(sh.stage, 8ull * o, src[i], 8 * vb);
+            stage_or(sh.stage, 8ull * o, src[i] & (vb >= 4 ? 0xffffffffu : (1u << (8 * vb)) - 1), 8 * vb);
             o += vb;
             i = j;
         }
@@ -601,6 +623,537 @@ __global__ __launch_bounds__(ET) void rle_encode_write_kernel(EncPage* __restric
         pg.out_bytes = bytes <= pg.dst_cap ? bytes : 0;
         pg.status = bytes <= pg.dst_cap ? PQD_OK : PQD_ERR_DST_TOO_SMALL;
         pg.arg = bytes <= pg.dst_cap ? 0 : (int64_t)bytes;
+    }
+}
+
+// ------------------------------------------------------------------- RLE levels --
+
+// encodeBytes (rle.go:141-201) takes the levels eight at a time, as 64-bit words.  A word all of
+// whose bytes are the same begins (or continues) a run of repeats; but a bit-packed run only ends
+// at a word that equals the broadcast of the LAST BYTE-0 of the word before it (rle.go:176-178), so
+// a uniform word inside a bit-packed run is swallowed unless the word before it starts with the
+// same byte.  Where runs begin therefore depends on whether the word before lies in a run of repeats
+// (R) or in a bit-packed run (B) -- a two-state machine whose per-word transition is one of three
+// functions: "R whatever came before" (the word equals the broadcast of its predecessor's first
+// byte), "B whatever came before" (it is not uniform), or "unchanged" (uniform, but another value:
+// after repeats it begins new repeats, inside a bit-packed run it is just more packed data).  The
+// state in front of a word is the value of the nearest word before it that is not "unchanged":
+// a ballot and a count of leading zeros inside a wavefront, a word per tile across tiles.
+enum : uint32_t { LV_B = 0, LV_R = 1, LV_I = 2 };
+constexpr uint32_t LV_WORDS = ET; // words (of eight levels) per workgroup, one per thread
+
+__device__ inline uint64_t lv_broadcast(uint64_t w) { return (w & 0xff) * 0x0101010101010101ull; }
+
+__device__ inline uint32_t lv_function(uint64_t w, uint64_t prev, bool have_prev) {
+    if (have_prev && w == lv_broadcast(prev)) return LV_R;
+    if (w != lv_broadcast(w)) return LV_B;
+    return have_prev ? LV_I : LV_R;
+}
+
+// The state in front of this lane's word: the nearest lower lane whose function is not LV_I decides, else `entered`.
+__device__ inline uint32_t lv_state_before(uint32_t fn, uint32_t lane, uint32_t entered) {
+    const unsigned long long set = __ballot(fn != LV_I), reps = __ballot(fn == LV_R);
+    const unsigned long long below = set & ((1ull << lane) - 1);
+    if (!below) return entered;
+    return (uint32_t)((reps >> (63 - __builtin_clzll(below))) & 1);
+}
+// What the 64 words of the wavefront do to the state together.
+__device__ inline uint32_t lv_wave_function(uint32_t fn) {
+    const unsigned long long set = __ballot(fn != LV_I), reps = __ballot(fn == LV_R);
+    if (!set) return LV_I;
+    return (uint32_t)((reps >> (63 - __builtin_clzll(set))) & 1);
+}
+
+__device__ inline uint64_t lv_load(gptr<const uint8_t> src, uint64_t w) { return *(gptr<const u64_a1e>)(src + 8 * w); }
+
+// Does a run begin at this word, entered in `before`?  And is it a run of repeats?
+__device__ inline bool lv_starts(uint32_t fn, uint32_t before, bool first_word) { return first_word || ((before == LV_R) != (fn == LV_R)); }
+
+struct LvShared {
+    uint32_t wave_fn[ET / 64];
+    unsigned long long starts[ET / 64];
+    uint32_t wave_total[ET / 64];
+    uint32_t first_r, first_b, any;
+    uint64_t before;
+    // per word at most a 5-byte run header and 8 packed bytes; a page of zeros' single header; seven one-value runs at the end
+    uint32_t stage[(LV_WORDS * 13 + 10 + 7 * 6) / 4 + 4];
+};
+
+// The state in front of every word of the tile, given the state the tile is entered in.
+__device__ inline uint32_t lv_tile_state_before(LvShared& sh, uint32_t fn, uint32_t entered) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t wf = lv_wave_function(fn);
+    if (lane == 0) sh.wave_fn[wave] = wf;
+    lds_sync();
+    uint32_t in = entered;
+    for (uint32_t w = 0; w < wave; w++) in = sh.wave_fn[w] == LV_I ? in : sh.wave_fn[w];
+    return lv_state_before(fn, lane, in);
+}
+
+// Pass one: per tile what it does to the state, the first run start for either state it may be entered in, and the OR of the levels.
+__global__ __launch_bounds__(ET) void levels_encode_scan_kernel(EncPage* __restrict__ pages, const uint32_t* __restrict__ items,
+                                                                const uint64_t* __restrict__ prefix, uint32_t n_pages) {
+    __shared__ LvShared sh;
+    uint32_t p;
+    uint64_t tile;
+    if (!page_and_tile(pages, items, prefix, n_pages, p, tile)) return;
+    EncPage& pg = pages[items[p]];
+    gptr<const uint8_t> src = as_global(pg.src);
+    const uint64_t n = pg.n_values, words = n / 8;
+    const uint64_t g = tile * LV_WORDS + threadIdx.x;
+    if (threadIdx.x == 0) { sh.first_r = RE_NONE; sh.first_b = RE_NONE; sh.any = 0; }
+    uint32_t fn = LV_I;
+    uint64_t w = 0;
+    if (g < words) {
+        w = lv_load(src, g);
+        fn = lv_function(w, g > 0 ? lv_load(src, g - 1) : 0, g > 0);
+    }
+    uint32_t any = (uint32_t)(w | (w >> 32));
+    if (tile + 1 == pg.n_tiles && threadIdx.x < (n & 7)) any |= src[words * 8 + threadIdx.x];
+    for (int o = 32; o > 0; o >>= 1) any |= __shfl_xor(any, o);
+    // entered in R and entered in B (the first word of the page begins a run either way)
+    const uint32_t before_r = lv_tile_state_before(sh, fn, LV_R);
+    lds_sync();
+    const uint32_t before_b = lv_tile_state_before(sh, fn, LV_B);
+    if (g < words) {
+        if (lv_starts(fn, before_r, g == 0)) atomicMin(&sh.first_r, (uint32_t)g);
+        if (lv_starts(fn, before_b, g == 0)) atomicMin(&sh.first_b, (uint32_t)g);
+    }
+    if ((threadIdx.x & 63) == 0 && any) atomicOr(&sh.any, any);
+    lds_sync();
+    if (threadIdx.x == 0) {
+        uint32_t tf = LV_I;
+        for (uint32_t k = 0; k < ET / 64; k++) tf = sh.wave_fn[k] == LV_I ? tf : sh.wave_fn[k];
+        pg.tile_fn[tile] = (uint8_t)tf;
+        pg.first_start[tile] = sh.first_r;
+        pg.first_start_b[tile] = sh.first_b;
+        if (sh.any) atomicOr(pg.or_word, sh.any);
+    }
+}
+
+// Pass two, one wavefront per page: forwards, the state every tile is entered in (which picks its first run
+// start); backwards, the first run start behind every tile.
+__global__ __launch_bounds__(64) void levels_encode_next_kernel(EncPage* __restrict__ pages, const uint32_t* __restrict__ items) {
+    EncPage& pg = pages[items[blockIdx.x]];
+    const uint32_t lane = threadIdx.x;
+    const uint64_t words = pg.n_values / 8;
+    uint32_t entered = LV_B; // (the first word of a page begins a run whatever this says)
+    for (uint64_t lo = 0; lo < pg.n_tiles; lo += 64) {
+        const uint64_t t = lo + lane;
+        const uint32_t fn = t < pg.n_tiles ? pg.tile_fn[t] : LV_I;
+        const uint32_t before = lv_state_before(fn, lane, entered);
+        const uint32_t all = lv_wave_function(fn);
+        if (t < pg.n_tiles) {
+            pg.tile_fn[t] = (uint8_t)before;
+            if (before == LV_B) pg.first_start[t] = pg.first_start_b[t];
+        }
+        entered = all == LV_I ? entered : all;
+    }
+    __threadfence(); // other lanes read below what these lanes wrote
+    uint32_t carry = (uint32_t)words;
+    for (uint64_t hi = pg.n_tiles; hi > 0; hi -= std::min<uint64_t>(64, hi)) {
+        const uint32_t look = (uint32_t)std::min<uint64_t>(64, hi);
+        const uint64_t t = hi - 1 - lane;
+        uint32_t mine = lane < look ? pg.first_start[t] : RE_NONE;
+        uint32_t incl = mine;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t up = __shfl_up(incl, o);
+            if (lane >= (uint32_t)o) incl = std::min(incl, up);
+        }
+        uint32_t excl = __shfl_up(incl, 1);
+        if (lane == 0) excl = RE_NONE;
+        if (lane < look) pg.next_start[t] = std::min(excl, carry);
+        carry = std::min(carry, lane_u32(incl, 63));
+    }
+}
+
+// Pass three: the page bytes (appendRunLengthBytes / appendBitPackedBytes, rle.go:470-484, 532-548).
+__global__ __launch_bounds__(ET) void levels_encode_write_kernel(EncPage* __restrict__ pages, const uint32_t* __restrict__ items,
+                                                                 const uint64_t* __restrict__ prefix, uint32_t n_pages,
+                                                                 unsigned long long* __restrict__ state) {
+    __shared__ LvShared sh;
+    uint32_t p;
+    uint64_t tile;
+    if (!page_and_tile(pages, items, prefix, n_pages, p, tile)) return;
+    EncPage& pg = pages[items[p]];
+    gptr<const uint8_t> src = as_global(pg.src);
+    const uint64_t n = pg.n_values, words = n / 8;
+    const uint64_t g = tile * LV_WORDS + threadIdx.x;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint32_t bw = pg.fixed_bw;
+    const bool last_tile = tile + 1 == pg.n_tiles;
+    if (bw > 8 || (bw == 0 && *pg.or_word != 0)) { // rle.go:142-149 (every tile of the page leaves here: nobody waits for another)
+        if (last_tile && threadIdx.x == 0) { pg.status = PQD_ERR_INVALID_BIT_WIDTH; pg.arg = bw; pg.out_bytes = 0; }
+        return;
+    }
+    const bool have = g < words && bw > 0;
+    uint32_t fn = LV_I;
+    uint64_t w = 0;
+    if (have) {
+        w = lv_load(src, g);
+        fn = lv_function(w, g > 0 ? lv_load(src, g - 1) : 0, g > 0);
+    }
+    const uint32_t before = lv_tile_state_before(sh, fn, pg.tile_fn[tile]);
+    const bool start = have && lv_starts(fn, before, g == 0);
+    const bool repeats = fn != LV_B; // the kind of the run that begins here, if one does
+    const bool in_repeats = start ? repeats : before == LV_R; // the kind of the run this word lies in
+    const unsigned long long mask = __ballot(start);
+    if (lane == 0) sh.starts[wave] = mask;
+    for (uint32_t i = threadIdx.x; i < sizeof(sh.stage) / 4; i += ET) sh.stage[i] = 0;
+    lds_sync();
+    uint64_t run_words = 0;
+    if (start) {
+        uint64_t next = pg.next_start[tile];
+        unsigned long long m = lane == 63 ? 0ull : mask & (~0ull << (lane + 1));
+        for (uint32_t k = wave; ; k++) {
+            if (m) { next = tile * LV_WORDS + 64ull * k + (uint32_t)__builtin_ctzll(m); break; }
+            if (k + 1 >= ET / 64) break;
+            m = sh.starts[k + 1];
+        }
+        run_words = next - g;
+    }
+    uint32_t hdr = 0, mine = 0;
+    if (have) {
+        if (start) hdr = uvarint_len(repeats ? (8 * run_words) << 1 : (run_words << 1) | 1);
+        mine = hdr + (in_repeats ? (start ? 1u : 0u) : bw);
+    }
+    const uint32_t incl = wave_inclusive_scan(mine);
+    if (lane == 63) sh.wave_total[wave] = incl;
+    lds_sync();
+    uint32_t off = incl - mine, words_total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < ET / 64; k++) {
+        if (k < wave) off += sh.wave_total[k];
+        words_total += sh.wave_total[k];
+    }
+    const uint32_t head = tile == 0 && bw == 0 ? uvarint_len(n << 1) : 0; // a page of zeros at width 0: one header, no value
+    uint32_t tail_bytes = 0;
+    if (last_tile && bw > 0) {
+        for (uint64_t i = words * 8; i < n;) { // the levels behind the last whole word: runs of repeats (rle.go:188-198)
+            uint64_t j = i + 1;
+            while (j < n && src[j] == src[i]) j++;
+            tail_bytes += uvarint_len((j - i) << 1) + 1;
+            i = j;
+        }
+    }
+    const uint32_t total = head + words_total + tail_bytes;
+    if (wave == 0) {
+        const uint64_t bytes_before = tile_prefix(state + pg.tile_base, tile, total, lane);
+        if (lane == 0) sh.before = bytes_before;
+    }
+    if (tile == 0 && bw == 0 && threadIdx.x == 0) stage_uvarint(sh.stage, 0, n << 1);
+    if (have) {
+        uint32_t o = head + off;
+        if (start) o += stage_uvarint(sh.stage, o, repeats ? (8 * run_words) << 1 : (run_words << 1) | 1);
+        if (in_repeats) {
+            if (start) stage_or(sh.stage, 8ull * o, w & 0xff, 8);
+        } else { // encodeBytesBitpackDefault (rle.go:532-548): the low bw bits of every byte
+            const uint64_t fm = (1ull << bw) - 1;
+            uint64_t packed = 0;
+#pragma unroll
+            for (uint32_t e = 0; e < 8; e++) packed |= ((w >> (8 * e)) & fm) << (e * bw);
+            stage_or(sh.stage, 8ull * o, packed, 8 * bw);
+        }
+    }
+    if (last_tile && bw > 0 && threadIdx.x == 0) {
+        uint32_t o = head + words_total;
+        for (uint64_t i = words * 8; i < n;) {
+            uint64_t j = i + 1;
+            while (j < n && src[j] == src[i]) j++;
+            o += stage_uvarint(sh.stage, o, (j - i) << 1);
+            stage_or(sh.stage, 8ull * o, src[i], 8);
+            o += 1;
+            i = j;
+        }
+    }
+    lds_sync();
+    const uint64_t bytes_before = sh.before;
+    if (bytes_before + total <= pg.dst_cap) stage_flush(as_global(pg.dst), bytes_before, sh.stage, total);
+    if (last_tile && threadIdx.x == 0) {
+        const uint64_t bytes = bytes_before + total;
+        pg.out_bytes = bytes <= pg.dst_cap ? bytes : 0;
+        pg.status = bytes <= pg.dst_cap ? PQD_OK : PQD_ERR_DST_TOO_SMALL;
+        pg.arg = bytes <= pg.dst_cap ? 0 : (int64_t)bytes;
+    }
+}
+
+// ----------------------------------------------------------------- RLE booleans --
+
+// encodeBits (rle.go:97-139) over the packed bits, behind the 4-byte length EncodeBoolean puts in front
+// (rle.go:48-56).  Where a run ends depends on where it began and on what kind it is, byte by byte; a
+// boolean page is an eighth of a byte per value, so this first form walks it with one lane per page:
+// long stretches of equal bytes are skipped eight at a time.  Two passes of the same walk: sizes, then bytes.
+__device__ inline uint64_t bits_encode_walk(gptr<const uint8_t> src, uint64_t n, gptr<uint8_t> dst, bool write) {
+    uint64_t o = 0;
+    auto put_uvarint = [&](uint64_t v) {
+        while (v >= 0x80) { if (write) dst[o] = (uint8_t)(v | 0x80); o++; v >>= 7; }
+        if (write) dst[o] = (uint8_t)v;
+        o++;
+    };
+    auto same_until = [&](uint64_t i) { // first j > i with src[j] != src[i]
+        const uint8_t b = src[i];
+        const uint64_t bb = (uint64_t)b * 0x0101010101010101ull;
+        uint64_t j = i + 1;
+        while (j + 8 <= n && *(gptr<const u64_a1e>)(src + j) == bb) j += 8;
+        while (j < n && src[j] == b) j++;
+        return j;
+    };
+    bool uniform = n == 0;
+    if (n > 0 && (src[0] == 0 || src[0] == 0xff)) uniform = same_until(0) == n;
+    if (uniform) { // rle.go:98-104
+        put_uvarint((8 * n) << 1);
+        if (n > 0) { if (write) dst[o] = src[0]; o++; }
+        return o;
+    }
+    for (uint64_t i = 0; i < n;) {
+        uint64_t j = i + 1;
+        if (src[i] == 0 || src[i] == 0xff) {
+            j = same_until(i);
+            if (j - i > 1) {
+                put_uvarint((8 * (j - i)) << 1);
+                if (write) dst[o] = src[i];
+                o++;
+                i = j;
+                continue;
+            }
+        }
+        while (j < n && (src[j - 1] != src[j] || src[j] == 0xff)) j++; // rle.go:125: `src[j] != 0 && src[j] == 0xFF`
+        if (j - i > 1 && j < n) j--;
+        put_uvarint(((j - i) << 1) | 1);
+        if (write) for (uint64_t k = i; k < j; k++) dst[o + (k - i)] = src[k];
+        o += j - i;
+        i = j;
+    }
+    return o;
+}
+
+__global__ __launch_bounds__(64) void bits_encode_kernel(EncPage* __restrict__ pages, const uint32_t* __restrict__ items, uint32_t n_items) {
+    const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= n_items) return;
+    EncPage& pg = pages[items[k]];
+    gptr<const uint8_t> src = as_global(pg.src);
+    gptr<uint8_t> dst = as_global(pg.dst);
+    const uint64_t body = bits_encode_walk(src, pg.n_values, dst, false);
+    const uint64_t bytes = 4 + body;
+    if (bytes > pg.dst_cap) { pg.status = PQD_ERR_DST_TOO_SMALL; pg.arg = (int64_t)bytes; pg.out_bytes = 0; return; }
+    for (uint32_t b = 0; b < 4; b++) dst[b] = (uint8_t)((uint32_t)body >> (8 * b));
+    bits_encode_walk(src, pg.n_values, dst + 4, true);
+    pg.status = PQD_OK; pg.arg = 0; pg.out_bytes = bytes;
+}
+
+// ------------------------------------------------------------------ byte arrays --
+
+// Where value k lies in src, and how long it is.
+__device__ inline void ba_value(const EncPage& pg, uint64_t k, uint64_t& at, uint32_t& len) {
+    if (pg.offsets != nullptr) {
+        const u32x2_a4 e = *(gptr<const u32x2_a4>)(as_global(pg.offsets) + k);
+        at = e.x; len = e.y - e.x;
+    } else {
+        at = k * (uint64_t)pg.width; len = (uint32_t)pg.width;
+    }
+}
+
+// wordSearchPrefixLength (byte_array.go:206-228): the longest common prefix, eight bytes at a time.
+__device__ inline uint32_t ba_common_prefix(gptr<const uint8_t> a, uint32_t na, gptr<const uint8_t> b, uint32_t nb) {
+    const uint32_t n = na < nb ? na : nb;
+    uint32_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        const uint64_t x = *(gptr<const u64_a1e>)(a + i) ^ *(gptr<const u64_a1e>)(b + i);
+        if (x) return i + (uint32_t)(__builtin_ctzll(x) >> 3);
+    }
+    while (i < n && a[i] == b[i]) i++;
+    return i;
+}
+
+// The length streams: DELTA_LENGTH_BYTE_ARRAY's lengths (encodeByteArrayLengths, length_byte_array_purego.go:5-9), or
+// DELTA_BYTE_ARRAY's prefix and suffix lengths (byte_array.go:30-52, 97-105).  A thread per value.
+__global__ __launch_bounds__(ET) void ba_lengths_kernel(EncPage* __restrict__ pages, const uint32_t* __restrict__ items) {
+    const EncPage& pg = pages[items[blockIdx.x]];
+    gptr<const uint8_t> src = as_global(pg.src);
+    gptr<int32_t> la = as_global(pg.len_a), lb = as_global(pg.len_b);
+    for (uint64_t k = (uint64_t)blockIdx.y * ET + threadIdx.x; k < pg.n_values; k += (uint64_t)gridDim.y * ET) {
+        uint64_t at;
+        uint32_t len;
+        ba_value(pg, k, at, len);
+        if (pg.family == EF_DLBA) { la[k] = (int32_t)len; continue; }
+        uint32_t pre = 0;
+        if (k > 0) {
+            uint64_t pat;
+            uint32_t plen;
+            ba_value(pg, k - 1, pat, plen);
+            pre = ba_common_prefix(src + pat, plen, src + at, len);
+        }
+        la[k] = (int32_t)pre;
+        lb[k] = (int32_t)(len - pre);
+    }
+}
+
+// What an internal length-stream item came to: its bytes, or -1 for an error that is not about room.
+__device__ inline int64_t stream_size(const EncPage& s) {
+    if (s.status == PQD_OK) return (int64_t)s.out_bytes;
+    if (s.status == PQD_ERR_DST_TOO_SMALL) return s.arg;
+    return -1;
+}
+
+// Between the two length streams of DELTA_BYTE_ARRAY pages: the second goes behind the first.
+__global__ __launch_bounds__(64) void ba_chain_kernel(EncPage* __restrict__ pages, const uint32_t* __restrict__ items, uint32_t n_items) {
+    const uint32_t k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= n_items) return;
+    EncPage& pg = pages[items[k]];
+    const EncPage& a = pages[pg.chain_a];
+    EncPage& b = pages[pg.chain_b];
+    const int64_t sa = stream_size(a);
+    const bool fits = a.status == PQD_OK && (uint64_t)sa <= pg.dst_cap;
+    b.dst = fits ? pg.dst + sa : pg.dst;
+    b.dst_cap = fits ? pg.dst_cap - (uint64_t)sa : 0; // no room: the stream is only sized
+}
+
+constexpr uint32_t BA_IMG = 8192; // output bytes of 64 values that are put together in LDS
+
+// 64 neighbouring values by one wavefront: lane l moves `len` bytes from src + from to dst + to, `head` says whether the
+// value's length goes in front of it as four bytes (PLAIN).  The outputs of the 64 follow one another, so they are put
+// together in an LDS image that agrees with the destination modulo 16 and leave in whole 16-byte stores.
+__device__ inline void ba_copy64(gptr<const uint8_t> src, gptr<uint8_t> dst, uint64_t from, uint32_t len, uint64_t to, bool head, uint32_t cnt,
+                                 uint8_t* img) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t hb = head ? 4u : 0u;
+    const uint64_t to0 = lane_u64(to, 0);
+    const uint64_t total = lane_u64(to, cnt - 1) + lane_u32(len, cnt - 1) + hb - to0;
+    if (total > BA_IMG) { // long values: one after the other, a lane per byte
+        for (uint32_t v = 0; v < cnt; v++) {
+            const uint32_t n = lane_u32(len, v);
+            gptr<const uint8_t> s = src + lane_u64(from, v);
+            gptr<uint8_t> d = dst + lane_u64(to, v);
+            if (head && lane < 4) d[lane] = (uint8_t)(n >> (8 * lane));
+            for (uint32_t b = lane; b < n; b += 64) d[hb + b] = s[b];
+        }
+        return;
+    }
+    const uint32_t align = (uint32_t)((uintptr_t)(dst + to0) & 15);
+    if (lane < cnt) {
+        uint8_t* q = img + align + (uint32_t)(to - to0);
+        if (head) { q[0] = (uint8_t)len; q[1] = (uint8_t)(len >> 8); q[2] = (uint8_t)(len >> 16); q[3] = (uint8_t)(len >> 24); q += 4; }
+        gptr<const uint8_t> s = src + from;
+        uint32_t b = 0;
+        for (; b + 4 <= len; b += 4) {
+            const uint32_t x = *(gptr<const u32_a1e>)(s + b);
+            q[b] = (uint8_t)x; q[b + 1] = (uint8_t)(x >> 8); q[b + 2] = (uint8_t)(x >> 16); q[b + 3] = (uint8_t)(x >> 24);
+        }
+        for (; b < len; b++) q[b] = s[b];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // one wavefront: its LDS operations execute in order
+    gptr<uint8_t> o = dst + to0;
+    const uint32_t bytes = (uint32_t)total;
+    const uint32_t lead = std::min(bytes, (16 - align) & 15);
+    const uint32_t whole = (bytes - lead) / 16, tail0 = lead + whole * 16;
+    if (lane < lead) o[lane] = img[align + lane];
+    if (tail0 + lane < bytes) o[tail0 + lane] = img[align + tail0 + lane];
+    for (uint32_t c = lane; c < whole; c += 64)
+        *(gptr<u32x4>)(o + lead + c * 16) = *reinterpret_cast<const u32x4*>(img + align + lead + c * 16);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
+// PLAIN byte arrays (plain.go:44-57, AppendByteArray): every value behind its length.  Value k goes to
+// offsets[k] - offsets[0] + 4 k: no sum to wait for.
+__global__ __launch_bounds__(ET) void plain_ba_encode_kernel(EncPage* __restrict__ pages, const uint32_t* __restrict__ items) {
+    __shared__ __attribute__((aligned(16))) uint8_t img[ET / 64][BA_IMG + 32];
+    EncPage& pg = pages[items[blockIdx.x]];
+    const uint64_t n = pg.n_values;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t first = 0, last = 0;
+    uint32_t l0;
+    if (n > 0) { ba_value(pg, 0, first, l0); ba_value(pg, n - 1, last, l0); last += l0; }
+    const uint64_t bytes = (last - first) + 4 * n;
+    if (bytes > pg.dst_cap) {
+        if (blockIdx.y == 0 && threadIdx.x == 0) { pg.status = PQD_ERR_DST_TOO_SMALL; pg.arg = (int64_t)bytes; pg.out_bytes = 0; }
+        return;
+    }
+    for (uint64_t k0 = ((uint64_t)blockIdx.y * (ET / 64) + wave) * 64; k0 < n; k0 += (uint64_t)gridDim.y * ET) {
+        const uint64_t k = k0 + lane;
+        uint64_t at = 0;
+        uint32_t len = 0;
+        if (k < n) ba_value(pg, k, at, len);
+        ba_copy64(as_global(pg.src), as_global(pg.dst), at, len, (at - first) + 4 * k, true, (uint32_t)std::min<uint64_t>(64, n - k0), img[wave]);
+    }
+    if (blockIdx.y == 0 && threadIdx.x == 0) { pg.status = PQD_OK; pg.arg = 0; pg.out_bytes = bytes; }
+}
+
+// Behind the length streams of a DELTA_LENGTH_BYTE_ARRAY or DELTA_BYTE_ARRAY page, one workgroup per page: the size of
+// the page, whether it fits, and for DELTA_BYTE_ARRAY where every suffix goes (an exclusive sum over len_b, in place).
+__global__ __launch_bounds__(ET) void ba_place_kernel(EncPage* __restrict__ pages, const uint32_t* __restrict__ items) {
+    __shared__ uint64_t wsum[ET / 64];
+    EncPage& pg = pages[items[blockIdx.x]];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool dba = pg.family == EF_DBA;
+    const int64_t sa = stream_size(pages[pg.chain_a]), sb = dba ? stream_size(pages[pg.chain_b]) : 0;
+    if (sa < 0 || sb < 0) { // an error of the length streams that is not about room (none is expected: lengths are non-negative int32)
+        if (threadIdx.x == 0) { const EncPage& bad = sa < 0 ? pages[pg.chain_a] : pages[pg.chain_b]; pg.status = bad.status; pg.arg = bad.arg; pg.out_bytes = 0; }
+        return;
+    }
+    uint64_t payload = pg.src_len; // DELTA_LENGTH_BYTE_ARRAY appends all of src (length_byte_array.go:33)
+    if (dba) {
+        gptr<int32_t> lb = as_global(pg.len_b);
+        uint64_t carry = 0;
+        for (uint64_t base = 0; base < pg.n_values; base += ET) {
+            const uint64_t k = base + threadIdx.x;
+            const uint64_t mine = k < pg.n_values ? (uint64_t)(uint32_t)lb[k] : 0;
+            const uint64_t x = wave_inclusive_scan<uint64_t>(mine);
+            if (lane == 63) wsum[wave] = x;
+            __syncthreads();
+            uint64_t before = carry, all = 0;
+            for (uint32_t w = 0; w < ET / 64; w++) {
+                if (w < wave) before += wsum[w];
+                all += wsum[w];
+            }
+            if (k < pg.n_values) lb[k] = (int32_t)(uint32_t)(before + x - mine); // (a page has less than 4 GB of values: offsets are uint32)
+            carry += all;
+            __syncthreads();
+        }
+        payload = carry;
+    }
+    if (threadIdx.x == 0) {
+        const uint64_t bytes = (uint64_t)sa + (uint64_t)sb + payload;
+        const bool fits = bytes <= pg.dst_cap && pages[pg.chain_a].status == PQD_OK && (!dba || pages[pg.chain_b].status == PQD_OK);
+        pg.status = fits ? PQD_OK : PQD_ERR_DST_TOO_SMALL;
+        pg.arg = fits ? 0 : (int64_t)bytes;
+        pg.out_bytes = fits ? bytes : 0;
+    }
+}
+
+// The bytes behind the length streams.
+__global__ __launch_bounds__(ET) void ba_payload_kernel(EncPage* __restrict__ pages, const uint32_t* __restrict__ items) {
+    __shared__ __attribute__((aligned(16))) uint8_t img[ET / 64][BA_IMG + 32];
+    const EncPage& pg = pages[items[blockIdx.x]];
+    if (pg.status != PQD_OK) return;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    gptr<const uint8_t> src = as_global(pg.src);
+    if (pg.family == EF_DLBA) {
+        gptr<uint8_t> out = as_global(pg.dst) + pages[pg.chain_a].out_bytes;
+        const uint64_t n = pg.src_len;
+        const uint64_t lead = std::min<uint64_t>(n, (16 - ((uintptr_t)out & 15)) & 15);
+        const uint64_t whole = (n - lead) / 16, tail0 = lead + whole * 16;
+        const uint64_t tid = (uint64_t)blockIdx.y * ET + threadIdx.x, step = (uint64_t)gridDim.y * ET;
+        if (tid < lead) out[tid] = src[tid];
+        if (tid < n - tail0) out[tail0 + tid] = src[tail0 + tid];
+        for (uint64_t c = tid; c < whole; c += step) {
+            const u32x4_a1e x = *(gptr<const u32x4_a1e>)(src + lead + c * 16);
+            *(gptr<u32x4>)(out + lead + c * 16) = u32x4{x.x, x.y, x.z, x.w};
+        }
+        return;
+    }
+    gptr<uint8_t> out = as_global(pg.dst) + pages[pg.chain_a].out_bytes + pages[pg.chain_b].out_bytes;
+    gptr<const int32_t> la = as_global((const int32_t*)pg.len_a), lb = as_global((const int32_t*)pg.len_b);
+    const uint64_t n = pg.n_values;
+    for (uint64_t k0 = ((uint64_t)blockIdx.y * (ET / 64) + wave) * 64; k0 < n; k0 += (uint64_t)gridDim.y * ET) {
+        const uint64_t k = k0 + lane;
+        uint64_t at = 0, to = 0;
+        uint32_t len = 0, pre = 0;
+        if (k < n) {
+            ba_value(pg, k, at, len);
+            pre = (uint32_t)la[k];
+            to = (uint32_t)lb[k];
+        }
+        ba_copy64(src, out, at + pre, len - pre, to, false, (uint32_t)std::min<uint64_t>(64, n - k0), img[wave]);
     }
 }
 
@@ -652,8 +1205,8 @@ __global__ __launch_bounds__(ET) void dict_bounds_kernel(const T* __restrict__ d
     Bound<T> b;
     b.lo = b.hi = T(); b.lo_at = b.hi_at = ~0ull;
     for (uint64_t i = (uint64_t)blockIdx.x * ET + threadIdx.x; i < n; i += (uint64_t)gridDim.x * ET) {
-        const uint32_t j = (uint32_t)indexes[i];
-        if ((uint64_t)j >= dict_len) { atomicMin(&status[1], (unsigned long long)i); continue; }
+        const uint64_t j = indexes != nullptr ? (uint64_t)(uint32_t)indexes[i] : i; // no indexes: the values of a page as they lie
+        if (j >= dict_len) { atomicMin(&status[1], (unsigned long long)i); continue; }
         bound_take(b, dict[j], i);
     }
     b = bound_reduce_workgroup(b, scratch);
@@ -680,7 +1233,7 @@ __global__ __launch_bounds__(ET) void dict_bounds_finish_kernel(const T* __restr
     status[1] = 0;
     T lo = T(), hi = T();
     if (n > 0) {
-        const T first = dict[(uint32_t)indexes[0]];
+        const T first = dict[indexes != nullptr ? (uint32_t)indexes[0] : 0u];
         if (first != first) lo = hi = first; // the comparisons never replace a NaN
         else { lo = b.lo; hi = b.hi; }
     }
@@ -697,16 +1250,22 @@ __global__ void dict_bounds_init_kernel(unsigned long long* status) {
 
 // The scratch an encode call needs, and where its parts lie.
 struct EncodePlan {
-    std::vector<EncPage> pages;
+    std::vector<EncPage> pages;             // the caller's pages, then the internal length-stream items of byte-array pages
     std::vector<uint32_t> fam_items[EF_N];
     std::vector<uint64_t> fam_prefix[EF_N]; // per family: first tile of each of its pages, and the total
-    uint64_t bss_max_values = 0;
+    uint64_t bss_max_values = 0, ba_max_values = 0, ba_max_bytes = 0;
     size_t o_pages = 0, o_items[EF_N] = {}, o_prefix[EF_N] = {}, o_state = 0, state_bytes = 0, upload_end = 0, total = 0;
-    size_t o_or = 0, o_first = 0, o_next = 0; // RLE_DICTIONARY: a word per page (inside the cleared block), two per tile
+    size_t o_or = 0, o_first = 0, o_next = 0; // RLE: a word per page (inside the cleared block), two per tile
+    size_t o_first_b = 0, o_tile_fn = 0;      // RLE levels: another word and a byte per tile
+    size_t o_len = 0;                         // byte arrays: the length streams' values
 };
+
+// Families whose pages are cut into tiles that look back over per-tile state words.
+static const int TILED_FAMILIES[] = {EF_DELTA32, EF_DELTA64, EF_RLE_DICT, EF_DELTA32_B, EF_LEVELS};
 
 static int32_t value_width(int32_t kind, int32_t bit_width) {
     switch (kind) {
+        case PQD_KIND_LEVELS: case PQD_KIND_BOOLEAN: case PQD_KIND_BYTE_ARRAY: return 1;
         case PQD_KIND_INT32: case PQD_KIND_FLOAT: return 4;
         case PQD_KIND_INT64: case PQD_KIND_DOUBLE: return 8;
         case PQD_KIND_INT96: return 12;
@@ -721,9 +1280,17 @@ static int32_t encode_family(int32_t encoding, int32_t kind, int32_t width) {
             return kind == PQD_KIND_INT32 ? EF_DELTA32 : kind == PQD_KIND_INT64 ? EF_DELTA64 : EF_NONE;
         case PQD_ENC_RLE_DICTIONARY:
             return kind == PQD_KIND_INT32 ? EF_RLE_DICT : EF_NONE;
+        case PQD_ENC_RLE: // rle.Encoding: EncodeLevels, EncodeBoolean, EncodeInt32 (rle.go:43-61)
+            return kind == PQD_KIND_LEVELS ? EF_LEVELS : kind == PQD_KIND_BOOLEAN ? EF_BOOL : kind == PQD_KIND_INT32 ? EF_RLE_DICT : EF_NONE;
         case PQD_ENC_BYTE_STREAM_SPLIT:
             if (kind == PQD_KIND_INT32 || kind == PQD_KIND_INT64 || kind == PQD_KIND_FLOAT || kind == PQD_KIND_DOUBLE) return EF_BSS;
             return kind == PQD_KIND_FIXED_LEN_BYTE_ARRAY && width > 0 && width <= 32767 ? EF_BSS : EF_NONE;
+        case PQD_ENC_PLAIN:
+            return kind == PQD_KIND_BYTE_ARRAY ? EF_PLAIN_BA : EF_NONE;
+        case PQD_ENC_DELTA_LENGTH_BYTE_ARRAY:
+            return kind == PQD_KIND_BYTE_ARRAY ? EF_DLBA : EF_NONE;
+        case PQD_ENC_DELTA_BYTE_ARRAY: // EncodeByteArray and EncodeFixedLenByteArray (byte_array.go:26-122)
+            return kind == PQD_KIND_BYTE_ARRAY || (kind == PQD_KIND_FIXED_LEN_BYTE_ARRAY && width > 0 && width <= 32767) ? EF_DBA : EF_NONE;
         default:
             return EF_NONE;
     }
@@ -735,9 +1302,19 @@ static size_t carve(size_t& off, size_t bytes) {
     return at;
 }
 
+static uint64_t delta_tiles(uint64_t n_values) {
+    const uint64_t blocks = n_values < 2 ? 0 : (n_values - 1 + DE_BLOCK - 1) / DE_BLOCK;
+    return std::max<uint64_t>(1, (blocks + DE_TILE_BLOCKS - 1) / DE_TILE_BLOCKS);
+}
+
 static void plan_encode(const pqd_encode_page* in, uint64_t n, EncodePlan& plan, bool with_pointers) {
     plan.pages.resize(n);
     for (int f = 0; f < EF_N; f++) plan.fam_prefix[f].assign(1, 0);
+    auto enlist = [&](uint32_t i) {
+        const EncPage& e = plan.pages[i];
+        plan.fam_items[e.family].push_back(i);
+        plan.fam_prefix[e.family].push_back(plan.fam_prefix[e.family].back() + e.n_tiles);
+    };
     for (uint64_t i = 0; i < n; i++) {
         EncPage& e = plan.pages[i];
         std::memset(&e, 0, sizeof e);
@@ -749,63 +1326,126 @@ static void plan_encode(const pqd_encode_page* in, uint64_t n, EncodePlan& plan,
         e.kind = in[i].kind;
         e.width = value_width(in[i].kind, in[i].bit_width);
         e.family = encode_family(e.encoding, e.kind, e.width);
-        if (with_pointers && ((e.src == nullptr && e.n_values > 0) || (e.dst == nullptr && e.dst_cap > 0))) {
-            e.family = EF_NONE;
-            e.status = PQD_ERR_INVALID_ARGUMENT;
+        e.offsets = in[i].offsets;
+        e.src_len = in[i].src_bytes;
+        e.chain_a = e.chain_b = 0xffffffffu;
+        e.fixed_bw = e.encoding == PQD_ENC_RLE ? (uint32_t)in[i].bit_width : 0xffffffffu;
+        const bool bytes_family = e.family == EF_PLAIN_BA || e.family == EF_DLBA || e.family == EF_DBA;
+        const bool fixed_len = e.kind == PQD_KIND_FIXED_LEN_BYTE_ARRAY;
+        auto refuse = [&](int32_t status, int64_t arg) { e.family = EF_NONE; e.status = status; e.arg = arg; };
+        if (with_pointers && ((e.src == nullptr && e.n_values > 0 && !bytes_family) || (e.dst == nullptr && e.dst_cap > 0))) {
+            refuse(PQD_ERR_INVALID_ARGUMENT, 0);
         } else if (e.family == EF_NONE) {
-            e.status = PQD_ERR_NOT_SUPPORTED; // encoding.NotSupported answers these (encoding/notsupported.go:116-160)
-        } else if (with_pointers && e.family != EF_BSS && ((uintptr_t)e.src & (uintptr_t)(e.width - 1)) != 0) {
-            e.family = EF_NONE;
-            e.status = PQD_ERR_INVALID_ARGUMENT; // typed values are aligned to their width, as a Go slice is
-            e.arg = (int64_t)((uintptr_t)e.src & (uintptr_t)(e.width - 1));
+            refuse(PQD_ERR_NOT_SUPPORTED, 0); // encoding.NotSupported answers these (encoding/notsupported.go:116-160)
+        } else if (e.encoding == PQD_ENC_RLE && e.kind != PQD_KIND_BOOLEAN && (in[i].bit_width < 0 || in[i].bit_width > (e.kind == PQD_KIND_LEVELS ? 8 : 32))) {
+            refuse(PQD_ERR_INVALID_BIT_WIDTH, in[i].bit_width); // rle.go:142-144, 204-206
+        } else if (with_pointers && e.family != EF_BSS && e.width > 1 && !bytes_family && ((uintptr_t)e.src & (uintptr_t)(e.width - 1)) != 0) {
+            refuse(PQD_ERR_INVALID_ARGUMENT, (int64_t)((uintptr_t)e.src & (uintptr_t)(e.width - 1))); // typed values are aligned to their width, as a Go slice is
         } else if (e.family != EF_BSS && e.n_values > 0x7fffffffull) {
-            e.family = EF_NONE;
-            e.status = PQD_ERR_INVALID_ARGUMENT; // the decoder refuses more values than MaxInt32 (binary_packed.go:447-449)
-            e.arg = (int64_t)e.n_values;
+            refuse(PQD_ERR_INVALID_ARGUMENT, (int64_t)e.n_values); // the decoder refuses more values than MaxInt32 (binary_packed.go:447-449)
+        } else if (bytes_family && !fixed_len && e.offsets == nullptr && e.n_values > 0) {
+            refuse(PQD_ERR_INVALID_ARGUMENT, 0);
+        } else if (bytes_family && with_pointers && e.src == nullptr && e.src_len > 0) {
+            refuse(PQD_ERR_INVALID_ARGUMENT, 0);
+        } else if (bytes_family && e.src_len > 0xffffffffull) {
+            refuse(PQD_ERR_INVALID_ARGUMENT, (int64_t)e.src_len); // offsets are uint32
+        } else if (e.family == EF_DBA && fixed_len && e.src_len != e.n_values * (uint64_t)e.width) {
+            refuse(PQD_ERR_INVALID_ARGUMENT, (int64_t)e.src_len); // ErrEncodeInvalidInputSize (byte_array.go:85-87)
+        } else if (e.family == EF_DLBA && e.offsets == nullptr) {
+            refuse(PQD_OK, 0); // no offsets at all: an empty page (length_byte_array.go:21-23)
         }
+        if (fixed_len) e.offsets = nullptr;
         if (e.family == EF_NONE) continue;
-        if (e.family == EF_DELTA32 || e.family == EF_DELTA64) {
-            const uint64_t blocks = e.n_values < 2 ? 0 : (e.n_values - 1 + DE_BLOCK - 1) / DE_BLOCK;
-            e.n_tiles = std::max<uint64_t>(1, (blocks + DE_TILE_BLOCKS - 1) / DE_TILE_BLOCKS);
-        } else if (e.family == EF_RLE_DICT) {
-            e.n_tiles = std::max<uint64_t>(1, (e.n_values / 8 + RE_GROUPS - 1) / RE_GROUPS);
-        } else if (e.family == EF_BSS) {
-            plan.bss_max_values = std::max(plan.bss_max_values, e.n_values);
+        if (e.family == EF_DELTA32 || e.family == EF_DELTA64) e.n_tiles = delta_tiles(e.n_values);
+        else if (e.family == EF_RLE_DICT) e.n_tiles = std::max<uint64_t>(1, (e.n_values / 8 + RE_GROUPS - 1) / RE_GROUPS);
+        else if (e.family == EF_LEVELS) e.n_tiles = std::max<uint64_t>(1, (e.n_values / 8 + LV_WORDS - 1) / LV_WORDS);
+        else if (e.family == EF_BSS) plan.bss_max_values = std::max(plan.bss_max_values, e.n_values);
+        if (bytes_family) {
+            plan.ba_max_values = std::max(plan.ba_max_values, e.n_values);
+            plan.ba_max_bytes = std::max(plan.ba_max_bytes, e.src_len);
         }
-        plan.fam_items[e.family].push_back((uint32_t)i);
-        plan.fam_prefix[e.family].push_back(plan.fam_prefix[e.family].back() + e.n_tiles);
+        enlist((uint32_t)i);
+    }
+    // the length streams of byte-array pages are DELTA int32 items of their own, behind the caller's pages: the first
+    // (lengths, or prefix lengths) goes to the head of the page, the second (suffix lengths) behind it once its size is known
+    size_t len_values = 0;
+    for (int f : {EF_DLBA, EF_DBA}) {
+        for (uint32_t i : plan.fam_items[f]) {
+            const int streams = f == EF_DBA ? 2 : 1;
+            for (int k = 0; k < streams; k++) {
+                EncPage s;
+                std::memset(&s, 0, sizeof s);
+                s.n_values = plan.pages[i].n_values;
+                s.dst = plan.pages[i].dst;
+                s.dst_cap = plan.pages[i].dst_cap;
+                s.encoding = PQD_ENC_DELTA_BINARY_PACKED;
+                s.kind = PQD_KIND_INT32;
+                s.width = 4;
+                s.family = k == 0 ? EF_DELTA32 : EF_DELTA32_B;
+                s.n_tiles = delta_tiles(s.n_values);
+                s.chain_a = s.chain_b = 0xffffffffu;
+                s.fixed_bw = 0xffffffffu;
+                (k == 0 ? plan.pages[i].chain_a : plan.pages[i].chain_b) = (uint32_t)plan.pages.size();
+                plan.pages.push_back(s);
+                enlist((uint32_t)plan.pages.size() - 1);
+                len_values += (s.n_values + 63) & ~(size_t)63;
+            }
+        }
     }
     // the state words of all tiled families lie in one block, cleared before every launch
     uint64_t tiles = 0;
-    for (int f : {EF_DELTA32, EF_DELTA64, EF_RLE_DICT}) {
-        for (size_t k = 0; k < plan.fam_items[f].size(); k++) {
-            plan.pages[plan.fam_items[f][k]].tile_base = tiles + plan.fam_prefix[f][k];
-        }
+    for (int f : TILED_FAMILIES) {
+        for (size_t k = 0; k < plan.fam_items[f].size(); k++) plan.pages[plan.fam_items[f][k]].tile_base = tiles + plan.fam_prefix[f][k];
         tiles += plan.fam_prefix[f].back();
     }
     size_t off = 0;
-    plan.o_pages = carve(off, n * sizeof(EncPage));
+    plan.o_pages = carve(off, plan.pages.size() * sizeof(EncPage));
     for (int f = 0; f < EF_N; f++) {
         plan.o_items[f] = carve(off, plan.fam_items[f].size() * sizeof(uint32_t));
         plan.o_prefix[f] = carve(off, plan.fam_prefix[f].size() * sizeof(uint64_t));
     }
     plan.upload_end = off;
-    const size_t n_rle = plan.fam_items[EF_RLE_DICT].size(), rle_tiles = plan.fam_prefix[EF_RLE_DICT].back();
+    const size_t n_rle = plan.fam_items[EF_RLE_DICT].size() + plan.fam_items[EF_LEVELS].size();
+    const size_t rle_tiles = plan.fam_prefix[EF_RLE_DICT].back() + plan.fam_prefix[EF_LEVELS].back();
     plan.state_bytes = tiles * sizeof(unsigned long long) + n_rle * sizeof(uint32_t);
     plan.o_state = carve(off, plan.state_bytes);
     plan.o_or = plan.o_state + tiles * sizeof(unsigned long long);
     plan.o_first = carve(off, rle_tiles * sizeof(uint32_t));
     plan.o_next = carve(off, rle_tiles * sizeof(uint32_t));
+    plan.o_first_b = carve(off, plan.fam_prefix[EF_LEVELS].back() * sizeof(uint32_t));
+    plan.o_tile_fn = carve(off, plan.fam_prefix[EF_LEVELS].back());
+    plan.o_len = carve(off, len_values * sizeof(int32_t));
     plan.total = off;
 }
 
 // Device addresses of the per-page scratch, once the workspace is known.
 static void place_scratch(EncodePlan& plan, uint8_t* ws) {
-    for (size_t k = 0; k < plan.fam_items[EF_RLE_DICT].size(); k++) {
-        EncPage& e = plan.pages[plan.fam_items[EF_RLE_DICT][k]];
-        e.or_word = reinterpret_cast<uint32_t*>(ws + plan.o_or) + k;
-        e.first_start = reinterpret_cast<uint32_t*>(ws + plan.o_first) + plan.fam_prefix[EF_RLE_DICT][k];
-        e.next_start = reinterpret_cast<uint32_t*>(ws + plan.o_next) + plan.fam_prefix[EF_RLE_DICT][k];
+    size_t page = 0, tile = 0;
+    for (int f : {EF_RLE_DICT, EF_LEVELS}) {
+        for (size_t k = 0; k < plan.fam_items[f].size(); k++) {
+            EncPage& e = plan.pages[plan.fam_items[f][k]];
+            e.or_word = reinterpret_cast<uint32_t*>(ws + plan.o_or) + page++;
+            e.first_start = reinterpret_cast<uint32_t*>(ws + plan.o_first) + tile + plan.fam_prefix[f][k];
+            e.next_start = reinterpret_cast<uint32_t*>(ws + plan.o_next) + tile + plan.fam_prefix[f][k];
+            if (f == EF_LEVELS) {
+                e.first_start_b = reinterpret_cast<uint32_t*>(ws + plan.o_first_b) + plan.fam_prefix[f][k];
+                e.tile_fn = ws + plan.o_tile_fn + plan.fam_prefix[f][k];
+            }
+        }
+        tile += plan.fam_prefix[f].back();
+    }
+    int32_t* len = reinterpret_cast<int32_t*>(ws + plan.o_len);
+    for (int f : {EF_DLBA, EF_DBA}) {
+        for (uint32_t i : plan.fam_items[f]) {
+            EncPage& e = plan.pages[i];
+            const size_t room = (e.n_values + 63) & ~(size_t)63;
+            e.len_a = len; len += room;
+            plan.pages[e.chain_a].src = reinterpret_cast<const uint8_t*>(e.len_a);
+            if (f == EF_DBA) {
+                e.len_b = len; len += room;
+                plan.pages[e.chain_b].src = reinterpret_cast<const uint8_t*>(e.len_b);
+            }
+        }
     }
 }
 
@@ -843,10 +1483,27 @@ uint64_t pqd_encode_bound(int encoding, int kind, int bit_width, uint64_t n_valu
             // the width byte; per group of eight at most a 5-byte run header and 32 bytes of packed values;
             // up to seven one-value runs at the end
             return kind == PQD_KIND_INT32 ? 16 + (n_values / 8) * 37 + 7 * 6 : 0;
+        case PQD_ENC_RLE:
+            // levels: per word of eight at most a 5-byte run header and 8 packed bytes, then up to seven one-value runs;
+            // booleans (n_values bytes of packed bits): the length, and per byte at most a one-byte header and the byte;
+            // int32 with the width given: as RLE_DICTIONARY without the width byte
+            if (kind == PQD_KIND_LEVELS) return 16 + (n_values / 8) * 13 + 7 * 6;
+            if (kind == PQD_KIND_BOOLEAN) return 16 + 2 * n_values;
+            return kind == PQD_KIND_INT32 ? 16 + (n_values / 8) * 37 + 7 * 6 : 0;
         case PQD_ENC_BYTE_STREAM_SPLIT:
             return n_values * (uint64_t)(width > 0 ? width : 0);
         default:
-            return 0;
+            return 0; // byte arrays: pqd_encode_bound_byte_array
+    }
+}
+
+uint64_t pqd_encode_bound_byte_array(int encoding, uint64_t n_values, uint64_t src_bytes) {
+    const uint64_t stream = 24 + (n_values < 2 ? 0 : (n_values - 1 + DE_BLOCK - 1) / DE_BLOCK) * (14 + (uint64_t)DE_BLOCK * 4);
+    switch (encoding) {
+        case PQD_ENC_PLAIN: return src_bytes + 4 * n_values;
+        case PQD_ENC_DELTA_LENGTH_BYTE_ARRAY: return stream + src_bytes;
+        case PQD_ENC_DELTA_BYTE_ARRAY: return 2 * stream + src_bytes;
+        default: return 0;
     }
 }
 
@@ -870,7 +1527,7 @@ int pqd_encode_batch(pqd_ctx* ctx, pqd_encode_page* pages, uint64_t n_pages, voi
         return PQD_ERR_DST_TOO_SMALL;
     place_scratch(plan, ws);
     std::vector<uint8_t> image(plan.upload_end, 0);
-    std::memcpy(image.data() + plan.o_pages, plan.pages.data(), n_pages * sizeof(EncPage));
+    std::memcpy(image.data() + plan.o_pages, plan.pages.data(), plan.pages.size() * sizeof(EncPage));
     for (int f = 0; f < EF_N; f++) {
         if (!plan.fam_items[f].empty())
             std::memcpy(image.data() + plan.o_items[f], plan.fam_items[f].data(), plan.fam_items[f].size() * sizeof(uint32_t));
@@ -891,21 +1548,55 @@ int pqd_encode_batch(pqd_ctx* ctx, pqd_encode_page* pages, uint64_t n_pages, voi
         if (np <= 65535 && most <= 0x7fffffffull && most * np <= tiles + tiles / 2) { grid = dim3((uint32_t)most, (uint32_t)np); prefix = nullptr; }
         else { grid = dim3((uint32_t)tiles); prefix = prefix_of(f); }
     };
-    for (int f : {EF_DELTA32, EF_DELTA64}) {
+    for (int f : TILED_FAMILIES)
+        if (plan.fam_prefix[f].back() > 0x7fffffffull) return PQD_ERR_INVALID_ARGUMENT;
+    // how many workgroups walk the values (or bytes) of one byte-array page
+    auto ba_grid_y = [&](uint64_t units, uint64_t per) { return (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (units + per - 1) / per), 2048); };
+    // the values of the length streams first: DELTA int32 items encode them below
+    for (int f : {EF_DLBA, EF_DBA})
+        if (!plan.fam_items[f].empty())
+            hipLaunchKernelGGL(ba_lengths_kernel, dim3((uint32_t)plan.fam_items[f].size(), ba_grid_y(plan.ba_max_values, ET)), dim3(ET), 0, s, d_pages, items_of(f));
+    auto launch_delta = [&](int f) {
         const uint64_t tiles = plan.fam_prefix[f].back();
-        if (tiles == 0) continue;
-        if (tiles > 0x7fffffffull) return PQD_ERR_INVALID_ARGUMENT;
+        if (tiles == 0) return;
         const uint32_t np = (uint32_t)plan.fam_items[f].size();
         dim3 grid;
         const uint64_t* prefix;
         tile_grid(f, grid, prefix);
-        if (f == EF_DELTA32)
-            hipLaunchKernelGGL(delta_encode_kernel<int32_t>, grid, dim3(ET), 0, s, d_pages, items_of(f), prefix, np, d_state);
-        else
+        if (f == EF_DELTA64)
             hipLaunchKernelGGL(delta_encode_kernel<int64_t>, grid, dim3(ET), 0, s, d_pages, items_of(f), prefix, np, d_state);
+        else
+            hipLaunchKernelGGL(delta_encode_kernel<int32_t>, grid, dim3(ET), 0, s, d_pages, items_of(f), prefix, np, d_state);
+    };
+    launch_delta(EF_DELTA32);
+    launch_delta(EF_DELTA64);
+    if (const uint32_t nd = (uint32_t)plan.fam_items[EF_DBA].size()) {
+        hipLaunchKernelGGL(ba_chain_kernel, dim3((nd + 63) / 64), dim3(64), 0, s, d_pages, items_of(EF_DBA), nd);
+        launch_delta(EF_DELTA32_B);
+    }
+    for (int f : {EF_DLBA, EF_DBA}) {
+        if (plan.fam_items[f].empty()) continue;
+        const uint32_t np = (uint32_t)plan.fam_items[f].size();
+        hipLaunchKernelGGL(ba_place_kernel, dim3(np), dim3(ET), 0, s, d_pages, items_of(f));
+        const uint32_t gy = f == EF_DLBA ? ba_grid_y(plan.ba_max_bytes, (uint64_t)ET * 64) : ba_grid_y(plan.ba_max_values, ET);
+        hipLaunchKernelGGL(ba_payload_kernel, dim3(np, gy), dim3(ET), 0, s, d_pages, items_of(f));
+    }
+    if (const uint32_t np = (uint32_t)plan.fam_items[EF_PLAIN_BA].size())
+        hipLaunchKernelGGL(plain_ba_encode_kernel, dim3(np, ba_grid_y(plan.ba_max_values, ET)), dim3(ET), 0, s, d_pages, items_of(EF_PLAIN_BA));
+    if (const uint32_t np = (uint32_t)plan.fam_items[EF_BOOL].size())
+        hipLaunchKernelGGL(bits_encode_kernel, dim3((np + 63) / 64), dim3(64), 0, s, d_pages, items_of(EF_BOOL), np);
+    if (plan.fam_prefix[EF_LEVELS].back()) {
+        const int f = EF_LEVELS;
+        const uint32_t np = (uint32_t)plan.fam_items[f].size();
+        dim3 grid;
+        const uint64_t* prefix;
+        tile_grid(f, grid, prefix);
+        hipLaunchKernelGGL(levels_encode_scan_kernel, grid, dim3(ET), 0, s, d_pages, items_of(f), prefix, np);
+        hipLaunchKernelGGL(levels_encode_next_kernel, dim3(np), dim3(64), 0, s, d_pages, items_of(f));
+        hipLaunchKernelGGL(levels_encode_write_kernel, grid, dim3(ET), 0, s, d_pages, items_of(f), prefix, np, d_state);
     }
     if (const uint64_t tiles = plan.fam_prefix[EF_RLE_DICT].back()) {
-        if (tiles > 0x7fffffffull) return PQD_ERR_INVALID_ARGUMENT;
+        (void)tiles;
         const int f = EF_RLE_DICT;
         const uint32_t np = (uint32_t)plan.fam_items[f].size();
         dim3 grid;
@@ -933,11 +1624,28 @@ int pqd_encode_batch(pqd_ctx* ctx, pqd_encode_page* pages, uint64_t n_pages, voi
     return PQD_OK;
 }
 
+static int bounds_device(pqd_ctx* ctx, int32_t kind, int32_t is_unsigned, const void* dict_dev, uint64_t dict_len,
+                         const int32_t* indexes_dev, uint64_t n, void* bounds_dev, void* workspace_dev, uint64_t workspace_bytes,
+                         int64_t* status_dev, void* hip_stream);
+
 int pqd_dict_bounds_device(pqd_ctx* ctx, int32_t kind, int32_t is_unsigned, const void* dict_dev, uint64_t dict_len,
                            const int32_t* indexes_dev, uint64_t n, void* bounds_dev, void* workspace_dev, uint64_t workspace_bytes,
                            int64_t* status_dev, void* hip_stream) {
+    if (indexes_dev == nullptr && n > 0) return PQD_ERR_INVALID_ARGUMENT;
+    return bounds_device(ctx, kind, is_unsigned, dict_dev, dict_len, indexes_dev, n, bounds_dev, workspace_dev, workspace_bytes, status_dev, hip_stream);
+}
+
+int pqd_page_bounds_device(pqd_ctx* ctx, int32_t kind, int32_t is_unsigned, const void* values_dev, uint64_t n, void* bounds_dev,
+                           void* workspace_dev, uint64_t workspace_bytes, int64_t* status_dev, void* hip_stream) {
+    if (values_dev == nullptr && n > 0) return PQD_ERR_INVALID_ARGUMENT;
+    return bounds_device(ctx, kind, is_unsigned, values_dev, n, nullptr, n, bounds_dev, workspace_dev, workspace_bytes, status_dev, hip_stream);
+}
+
+static int bounds_device(pqd_ctx* ctx, int32_t kind, int32_t is_unsigned, const void* dict_dev, uint64_t dict_len,
+                         const int32_t* indexes_dev, uint64_t n, void* bounds_dev, void* workspace_dev, uint64_t workspace_bytes,
+                         int64_t* status_dev, void* hip_stream) {
     if (ctx == nullptr || bounds_dev == nullptr || status_dev == nullptr || workspace_dev == nullptr ||
-        workspace_bytes < PQD_BOUNDS_WORKSPACE_BYTES || ((uintptr_t)workspace_dev & 15) != 0 || (indexes_dev == nullptr && n > 0))
+        workspace_bytes < PQD_BOUNDS_WORKSPACE_BYTES || ((uintptr_t)workspace_dev & 15) != 0)
         return PQD_ERR_INVALID_ARGUMENT;
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return PQD_ERR_DEVICE;

@@ -312,8 +312,11 @@ int pqd_encode_values(pqd_ctx* ctx, int encoding, int kind, int bit_width, const
         case PQD_KIND_INT32: case PQD_KIND_FLOAT: width = 4; break;
         case PQD_KIND_INT64: case PQD_KIND_DOUBLE: width = 8; break;
         case PQD_KIND_FIXED_LEN_BYTE_ARRAY: width = bit_width > 0 ? (uint64_t)bit_width : 0; break;
+        case PQD_KIND_LEVELS: case PQD_KIND_BOOLEAN: width = 1; break; // a level a byte; booleans: n_values bytes of packed bits
         default: break;
     }
+    if (kind == PQD_KIND_FIXED_LEN_BYTE_ARRAY && encoding == PQD_ENC_DELTA_BYTE_ARRAY) // EncodeFixedLenByteArray (byte_array.go:76-122)
+        return pqd_encode_byte_array(ctx, encoding, kind, bit_width, src, n_values * width, nullptr, n_values, dst, dst_cap, out_bytes, status_arg);
     DeviceGuard guard(ctx->device);
     if (!guard.ok) return PQD_ERR_DEVICE;
     Lease lease(ctx);
@@ -333,6 +336,47 @@ int pqd_encode_values(pqd_ctx* ctx, int encoding, int kind, int bit_width, const
         PQD_HIP(hipMemcpyAsync(d_io + o_src, h_io + o_src, src_bytes, hipMemcpyHostToDevice, ws->stream));
     }
     p.src = d_io + o_src;
+    p.dst = d_io + o_dst;
+    int rc = pqd_encode_batch(ctx, &p, 1, d_io + o_ws, scratch + 256, ws->stream);
+    if (rc != PQD_OK) return rc;
+    if (status_arg) *status_arg = p.status_arg;
+    if (p.status == PQD_OK && p.out_bytes) {
+        PQD_HIP(hipMemcpyAsync(h_io + o_dst, d_io + o_dst, p.out_bytes, hipMemcpyDeviceToHost, ws->stream));
+        PQD_HIP(hipStreamSynchronize(ws->stream));
+        std::memcpy(dst, h_io + o_dst, p.out_bytes);
+    }
+    if (out_bytes) *out_bytes = p.status == PQD_OK ? p.out_bytes : 0;
+    return p.status;
+}
+
+int pqd_encode_byte_array(pqd_ctx* ctx, int encoding, int kind, int type_length, const void* src, uint64_t src_bytes,
+                          const uint32_t* offsets, uint64_t n_values, uint8_t* dst, uint64_t dst_cap, uint64_t* out_bytes,
+                          int64_t* status_arg) {
+    if (out_bytes) *out_bytes = 0;
+    if (status_arg) *status_arg = 0;
+    if (ctx == nullptr || (src == nullptr && src_bytes > 0) || (dst == nullptr && dst_cap > 0)) return PQD_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return PQD_ERR_DEVICE;
+    Lease lease(ctx);
+    Workspace* ws = lease.ws;
+    if (ws == nullptr) return PQD_ERR_DEVICE;
+    pqd_encode_page p;
+    std::memset(&p, 0, sizeof p);
+    p.n_values = n_values; p.dst_cap = dst_cap; p.src_bytes = src_bytes;
+    p.encoding = encoding; p.kind = kind; p.bit_width = type_length;
+    const uint64_t off_bytes = offsets ? (n_values + 1) * 4 : 0;
+    p.offsets = offsets ? reinterpret_cast<const uint32_t*>(8) : nullptr; // (a stand-in while the workspace is sized: only its being there counts)
+    const uint64_t scratch = pqd_encode_workspace_size(&p, 1);
+    const size_t o_src = 0, o_off = pad256(src_bytes + 32), o_dst = o_off + pad256(off_bytes + 32), o_ws = o_dst + pad256(dst_cap + 32);
+    if (!ws->reserve_io(o_ws + scratch + 256)) return PQD_ERR_DEVICE;
+    uint8_t* d_io = static_cast<uint8_t*>(ws->d_io);
+    uint8_t* h_io = static_cast<uint8_t*>(ws->h_io);
+    if (src_bytes) std::memcpy(h_io + o_src, src, src_bytes);
+    if (off_bytes) std::memcpy(h_io + o_off, offsets, off_bytes);
+    if (src_bytes) PQD_HIP(hipMemcpyAsync(d_io + o_src, h_io + o_src, src_bytes, hipMemcpyHostToDevice, ws->stream));
+    if (off_bytes) PQD_HIP(hipMemcpyAsync(d_io + o_off, h_io + o_off, off_bytes, hipMemcpyHostToDevice, ws->stream));
+    p.src = d_io + o_src;
+    p.offsets = offsets ? reinterpret_cast<const uint32_t*>(d_io + o_off) : nullptr;
     p.dst = d_io + o_dst;
     int rc = pqd_encode_batch(ctx, &p, 1, d_io + o_ws, scratch + 256, ws->stream);
     if (rc != PQD_OK) return rc;

@@ -219,13 +219,15 @@ class Encoding:
         return values, offs
 
     # -- the Encode methods (encoding/encoding.go:29-41): dst is replaced, not appended to, as in the reference --
-    def _encode(self, kind: int, dtype, src, size: int = 0) -> bytes:
-        """One page through pqd_encode_values; the output buffer grows when the library asks (Go's append)."""
+    def _encode(self, kind: int, dtype, src, size: int = 0, width_arg: int = 0) -> bytes:
+        """One page through pqd_encode_values; the output buffer grows when the library asks (Go's append).
+        `size` is a FIXED_LEN_BYTE_ARRAY's type length, `width_arg` the BitWidth of an RLE codec."""
         L = lib()
         v = np.ascontiguousarray(src, dtype=dtype).reshape(-1)
         n = v.size // size if size else v.size
         if size and v.size % size:
             raise ErrInvalidArgument(self.NAME, STATUS.INVALID_ARGUMENT, v.size, f"cannot encode FIXED_LEN_BYTE_ARRAY from input of size {v.size}: invalid argument")
+        size = size or width_arg
         cap = max(64, int(L.pqd_encode_bound(self.CODE, kind, size, n)))
         nbytes, arg = C.c_uint64(0), C.c_int64(0)
         for _ in range(3):
@@ -269,6 +271,55 @@ class Encoding:
     def _enc_flba(self, dst, src, size):
         return self._encode(KIND.FIXED_LEN_BYTE_ARRAY, np.uint8, src, int(size))
 
+    def EncodeLevels(self, dst, src):
+        self._unsupported("LEVELS")
+
+    def EncodeBoolean(self, dst, src):
+        self._unsupported("BOOLEAN")
+
+    def EncodeByteArray(self, dst, src, offsets):
+        self._unsupported("BYTE_ARRAY")
+
+    def _enc_levels(self, dst, src):
+        return self._encode(KIND.LEVELS, np.uint8, src, width_arg=int(self.BitWidth))
+
+    def _enc_boolean(self, dst, src):
+        return self._encode(KIND.BOOLEAN, np.uint8, src)
+
+    def _enc_int32_width(self, dst, src):
+        return self._encode(KIND.INT32, np.int32, src, width_arg=int(self.BitWidth))
+
+    def _enc_byte_array(self, dst, src, offsets, kind: int = KIND.BYTE_ARRAY, size: int = 0) -> bytes:
+        """EncodeByteArray(dst, src, offsets): value k is src[offsets[k]:offsets[k + 1]] (encoding/values.go:47-52)."""
+        L = lib()
+        v = _bytes(src)
+        off = None if offsets is None else np.ascontiguousarray(offsets, dtype=np.uint32).reshape(-1)
+        if off is not None and off.size == 0:
+            off = None  # len(offsets) == 0: no values at all
+        n = (off.size - 1) if off is not None else (v.size // size if size else 0)
+        cap = max(64, int(L.pqd_encode_bound_byte_array(self.CODE, n, v.size)))
+        nbytes, arg = C.c_uint64(0), C.c_int64(0)
+        for _ in range(3):
+            out = np.empty(cap, np.uint8)
+            rc = L.pqd_encode_byte_array(self.ctx().handle, self.CODE, kind, size, _ptr(v), v.size, None if off is None else _ptr(off), n, _ptr(out),
+                                         out.size, C.byref(nbytes), C.byref(arg))
+            if rc == STATUS.DST_TOO_SMALL and arg.value > cap:
+                cap = arg.value
+                continue
+            break
+        if rc != STATUS.OK:
+            raise _error(self.NAME, rc, arg.value)
+        return out[: nbytes.value].tobytes()
+
+    def _enc_flba_prefix(self, dst, src, size):
+        size = int(size)
+        v = _bytes(src)
+        if size < 0 or size > 32767:  # encoding.MaxFixedLenByteArraySize (byte_array.go:81-83)
+            raise ErrInvalidArgument(self.NAME, STATUS.INVALID_ARGUMENT, size, "invalid argument")
+        if size == 0 or v.size % size:
+            raise ErrInvalidArgument(self.NAME, STATUS.INVALID_ARGUMENT, v.size, f"cannot encode FIXED_LEN_BYTE_ARRAY from input of size {v.size}: invalid argument")
+        return self._enc_byte_array(dst, v, None, KIND.FIXED_LEN_BYTE_ARRAY, size)
+
     def _estimate(self, src) -> int:
         s = _bytes(src)
         return int(lib().pqd_estimate_decode_byte_array_size(self.ctx().handle, self.CODE, _ptr(s), s.size))
@@ -286,6 +337,7 @@ class Plain(Encoding):
     DecodeByteArray = Encoding._byte_array
     DecodeFixedLenByteArray = Encoding._flba
     EstimateDecodeByteArraySize = Encoding._estimate
+    EncodeByteArray = Encoding._enc_byte_array
 
 
 class RLE(Encoding):
@@ -294,6 +346,9 @@ class RLE(Encoding):
     DecodeLevels = Encoding._levels
     DecodeBoolean = Encoding._boolean
     DecodeInt32 = Encoding._int32
+    EncodeLevels = Encoding._enc_levels
+    EncodeBoolean = Encoding._enc_boolean
+    EncodeInt32 = Encoding._enc_int32_width
 
 
 class RLEDictionary(Encoding):
@@ -331,6 +386,7 @@ class DeltaLengthByteArray(Encoding):
     NAME, CODE = "DELTA_LENGTH_BYTE_ARRAY", ENC.DELTA_LENGTH_BYTE_ARRAY
     DecodeByteArray = Encoding._byte_array
     EstimateDecodeByteArraySize = Encoding._estimate
+    EncodeByteArray = Encoding._enc_byte_array
 
 
 class DeltaByteArray(Encoding):
@@ -339,6 +395,8 @@ class DeltaByteArray(Encoding):
     DecodeByteArray = Encoding._byte_array
     DecodeFixedLenByteArray = Encoding._flba
     EstimateDecodeByteArraySize = Encoding._estimate
+    EncodeByteArray = Encoding._enc_byte_array
+    EncodeFixedLenByteArray = Encoding._enc_flba_prefix
 
 
 class ByteStreamSplit(Encoding):

@@ -191,17 +191,32 @@ def encode_pages(ctx: Context, jobs, device: int = 0, dst_slack: int = 0, misali
     L = lib()
     torch = _torch()
     pages, keep = [], []
-    for encoding, kind, values, bit_width in jobs:
+    for job in jobs:
+        encoding, kind, values, bit_width = job[:4]
+        offsets = job[4] if len(job) > 4 else None  # BYTE_ARRAY pages: n + 1 offsets into `values` (bytes)
         v = np.ascontiguousarray(values)
-        n = v.size // bit_width if kind == 8 else v.size
         src = to_device(v, device, src_misalign)
-        cap = max(0, int(L.pqd_encode_bound(encoding, kind, bit_width, n)) + dst_slack)
-        dst = DeviceBuffer(cap, device, misalign, fill=0xA5)
         p = EncodePage()
+        off = None
+        if kind == KIND.BYTE_ARRAY or (kind == KIND.FIXED_LEN_BYTE_ARRAY and encoding == 7):
+            v = v.view(np.uint8).reshape(-1)
+            if offsets is not None:
+                o = np.ascontiguousarray(offsets, dtype=np.uint32)
+                n = max(o.size - 1, 0)
+                off = to_device(o if o.size else np.zeros(1, np.uint32), device)
+                p.offsets = off.ptr
+            else:
+                n = v.size // bit_width if kind == KIND.FIXED_LEN_BYTE_ARRAY and bit_width > 0 else 0
+            p.src_bytes = v.size
+            cap = max(0, int(L.pqd_encode_bound_byte_array(encoding, n, v.size)) + dst_slack)
+        else:
+            n = v.size // bit_width if kind == KIND.FIXED_LEN_BYTE_ARRAY else v.size
+            cap = max(0, int(L.pqd_encode_bound(encoding, kind, bit_width, n)) + dst_slack)
+        dst = DeviceBuffer(cap, device, misalign, fill=0xA5)
         p.src, p.n_values, p.dst, p.dst_cap = src.ptr, n, dst.ptr, cap
         p.encoding, p.kind, p.bit_width = encoding, kind, bit_width
         pages.append(p)
-        keep.append((src, dst))
+        keep.append((src, dst, off))
     arr = (EncodePage * max(len(pages), 1))(*pages)
     ws_bytes = int(L.pqd_encode_workspace_size(arr, len(pages)))
     ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=f"cuda:{device}")
@@ -210,7 +225,7 @@ def encode_pages(ctx: Context, jobs, device: int = 0, dst_slack: int = 0, misali
     if rc != STATUS.OK:
         raise PqdError(rc, 0, "pqd_encode_batch")
     out = []
-    for i, (src, dst) in enumerate(keep):
+    for i, (src, dst, _) in enumerate(keep):
         raw = dst.numpy()
         out.append((arr[i].status, arr[i].status_arg, raw[: arr[i].out_bytes].tobytes(), raw))
     return out

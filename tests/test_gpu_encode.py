@@ -219,3 +219,272 @@ def test_dictionary_bounds():
             wlo, whi = _bounds(d, idx)
             assert st == 0
             assert np.array([lo, hi], dtype).tobytes() == np.array([wlo, whi], dtype).tobytes(), (dtype, idx[:6], lo, hi, wlo, whi)
+
+
+# ---- RLE levels / booleans / int32 with the width given, and the byte-array encoders ----
+
+def _level_inputs(rng, bw):
+    hi = 1 << bw if bw else 1
+    out = []
+    for n in (0, 1, 7, 8, 9, 15, 16, 17, 64, 2047, 2048, 2049, 2056, 5000, 40003):
+        out.append((f"random-n{n}", rng.integers(0, hi, size=n, dtype=np.uint8)))
+    # runs of words, words that are uniform inside bit-packed runs, a uniform word behind a word that starts with the same byte
+    # (rle.go:176-178 compares a word with the broadcast of its predecessor's FIRST byte)
+    for n in (64, 3000, 20000, 70000):
+        v = np.empty(n, np.uint8)
+        at = 0
+        while at < n:
+            k = int(rng.choice([1, 2, 3, 7, 8, 9, 16, 24, 40, 64, 200, 3000]))
+            kind = int(rng.integers(0, 3))
+            if kind == 0:
+                v[at: at + k] = rng.integers(0, hi)
+            elif kind == 1:
+                v[at: at + k] = rng.integers(0, hi, size=min(k, n - at))
+            else:
+                a, b = rng.integers(0, hi, size=2)
+                seg = np.full(min(k, n - at), a, np.uint8)
+                seg[::8] = b  # every word starts with b and goes on with a
+                v[at: at + k] = seg
+            at += k
+        out.append((f"runs-n{n}", v))
+    w = np.zeros(8 * 600, np.uint8)
+    for i in range(600):  # all four (uniform?, equals the broadcast of the byte before?) cases side by side
+        first = rng.integers(0, hi)
+        w[8 * i: 8 * i + 8] = first if rng.integers(0, 2) else rng.integers(0, hi, size=8)
+        if rng.integers(0, 3) == 0 and i > 0:
+            w[8 * i: 8 * i + 8] = w[8 * (i - 1)]
+    out.append(("word-cases", w))
+    out.append(("zeros", np.zeros(4100, np.uint8)))
+    out.append(("ones-tail", np.concatenate([np.full(4096, hi - 1, np.uint8), rng.integers(0, hi, size=5, dtype=np.uint8)])))
+    return out
+
+
+@pytest.mark.parametrize("bw", [0, 1, 2, 3, 5, 8])
+def test_rle_levels_bytes(bw):
+    P = pkg()
+    rng = np.random.default_rng(20 + bw)
+    cases = _level_inputs(rng, bw)
+    for misalign in (0, 5):
+        outs = _encode([(P.ENC.RLE, P.KIND.LEVELS, v, bw) for _, v in cases], misalign=misalign, src_misalign=misalign)
+        for (label, v), (status, arg, page, raw) in zip(cases, outs):
+            want = bytes(O.rle_encode_levels(v, bw))
+            assert status == 0, (label, status, arg)
+            assert page == want, (label, len(page), len(want), next((i for i, (a, b) in enumerate(zip(page, want)) if a != b), None))
+            assert (raw[len(page):] == 0xA5).all(), label
+    specs = [spec(P.ENC.RLE, P.KIND.LEVELS, page, bit_width=bw, dst_cap=v.size + 64) for (_, v), (_, _, page, _) in zip(cases, outs) if v.size]
+    for (label, v), out in zip([c for c in cases if c[1].size], decode(specs)):
+        assert out.status == 0 and np.array_equal(out.data[: v.size], v & ((1 << bw) - 1)), label
+
+
+def test_rle_levels_refused_widths():
+    P = pkg()
+    outs = _encode([(P.ENC.RLE, P.KIND.LEVELS, np.zeros(20, np.uint8), 9), (P.ENC.RLE, P.KIND.LEVELS, np.array([0, 0, 1] * 10, np.uint8), 0),
+                    (P.ENC.RLE, P.KIND.INT32, np.zeros(20, np.int32), 33), (P.ENC.RLE, P.KIND.INT32, np.array([0, 5] * 10, np.int32), 0)])
+    assert [o[:2] for o in outs] == [(P.STATUS.INVALID_BIT_WIDTH, 9), (P.STATUS.INVALID_BIT_WIDTH, 0), (P.STATUS.INVALID_BIT_WIDTH, 33),
+                                     (P.STATUS.INVALID_BIT_WIDTH, 0)]
+
+
+@pytest.mark.parametrize("bw", [0, 1, 4, 7, 8, 13, 16, 25, 32])
+def test_rle_int32_with_the_width_given(bw):
+    P = pkg()
+    rng = np.random.default_rng(40 + bw)
+    cases = []
+    for n in (0, 1, 8, 9, 100, 2048, 2055, 30000):
+        v = rng.integers(0, 1 << bw if bw else 1, size=n, dtype=np.int64).astype(np.uint32).view(np.int32)
+        cases.append(v)
+        r = v.copy()
+        for k in range(0, n, 97):
+            r[k: k + int(rng.integers(1, 60))] = r[k]
+        cases.append(r)
+    outs = _encode([(P.ENC.RLE, P.KIND.INT32, v, bw) for v in cases])
+    for v, (status, arg, page, raw) in zip(cases, outs):
+        assert status == 0 and page == bytes(O.rle_encode_int32(v, bw)), (v.size, status, arg)
+
+
+def test_rle_boolean_bytes():
+    P = pkg()
+    rng = np.random.default_rng(50)
+    cases = [np.zeros(0, np.uint8), np.zeros(1, np.uint8), np.full(300, 0xFF, np.uint8), np.zeros(5000, np.uint8)]
+    for n in (1, 2, 3, 9, 100, 4097, 20000):
+        cases.append(rng.integers(0, 256, size=n, dtype=np.uint8))
+        # stretches of 0x00, 0xFF and of other repeated bytes (rle.go:125 treats 0xFF pairs unlike 0x00 pairs)
+        v = rng.choice(np.array([0, 0, 0xFF, 0xFF, 0x55, 0x55, 1, 0x80], np.uint8), size=n)
+        for k in range(0, n, 13):
+            v[k: k + int(rng.integers(1, 12))] = v[k]
+        cases.append(v)
+        cases.append(np.repeat(rng.choice(np.array([0, 0xFF, 7], np.uint8), size=n // 3 + 1), 3)[:n])
+    outs = _encode([(P.ENC.RLE, P.KIND.BOOLEAN, v, 0) for v in cases], misalign=1)
+    for k, (v, (status, arg, page, raw)) in enumerate(zip(cases, outs)):
+        want = bytes(O.rle_encode_boolean(v))
+        assert status == 0 and page == want, (k, v.size, status, arg, len(page), len(want))
+        assert (raw[len(page):] == 0xA5).all(), k
+    specs = [spec(P.ENC.RLE, P.KIND.BOOLEAN, page, dst_cap=v.size + 64) for v, (_, _, page, _) in zip(cases, outs)]
+    for k, (v, out) in enumerate(zip(cases, decode(specs))):
+        assert out.status == 0 and np.array_equal(out.data[: v.size], v), k
+
+
+def _strings(rng, kind, n):
+    if kind == "urls":
+        hosts = [b"https://www.example.com/products/category/", b"https://cdn.example.org/static/images/thumbs/2024/", b"http://a.b/"]
+        return sorted(hosts[int(rng.integers(0, 3))] + b"%08d" % int(rng.integers(0, 10**8)) for _ in range(n))
+    if kind == "random":
+        return [bytes(rng.integers(0, 256, size=int(rng.integers(0, 22)), dtype=np.uint8)) for _ in range(n)]
+    if kind == "long":
+        base = bytes(rng.integers(0, 256, size=3000, dtype=np.uint8))
+        return [base[: int(rng.integers(0, 3000))] + bytes(rng.integers(0, 256, size=int(rng.integers(0, 40)), dtype=np.uint8)) for _ in range(n)]
+    if kind == "empty":
+        return [b""] * n
+    if kind == "same":
+        return [b"the same value every time"] * n
+    raise ValueError(kind)
+
+
+def _byte_array_cases(rng):
+    cases = []
+    for kind in ("urls", "random", "long", "empty", "same"):
+        for n in (0, 1, 2, 63, 64, 65, 129, 1000, 5003):
+            if kind == "long" and n > 1000:
+                continue
+            data, offs = O._flatten(_strings(rng, kind, n))
+            cases.append((f"{kind}-n{n}", data, offs))
+    return cases
+
+
+@pytest.mark.parametrize("enc_name", ["PLAIN", "DELTA_LENGTH_BYTE_ARRAY", "DELTA_BYTE_ARRAY"])
+def test_byte_array_encoders_bytes(enc_name):
+    P = pkg()
+    rng = np.random.default_rng(60)
+    cases = _byte_array_cases(rng)
+    enc = getattr(P.ENC, enc_name)
+    oracle = {"PLAIN": lambda d, o: O._enc(O.lib().pqo_plain_encode_byte_array, d.size + 4 * o.size + 16, O._p(d), O._p(o), o.size),
+              "DELTA_LENGTH_BYTE_ARRAY": lambda d, o: O.dlba_encode(data=d, offsets=o),
+              "DELTA_BYTE_ARRAY": lambda d, o: O.dba_encode(data=d, offsets=o)}[enc_name]
+    for misalign in (0, 7):
+        outs = _encode([(enc, P.KIND.BYTE_ARRAY, d, 0, o) for _, d, o in cases], misalign=misalign, src_misalign=misalign)
+        for (label, d, o), (status, arg, page, raw) in zip(cases, outs):
+            want = bytes(oracle(d, o))
+            assert status == 0, (label, status, arg)
+            assert page == want, (label, len(page), len(want), next((i for i, (a, b) in enumerate(zip(page, want)) if a != b), None))
+            assert (raw[len(page):] == 0xA5).all(), label
+    # and the GPU decoders read them back
+    specs = [spec(enc, P.KIND.BYTE_ARRAY, page, dst_cap=d.size + 64, offsets_cap=o.size + 1) for (_, d, o), (_, _, page, _) in zip(cases, outs)]
+    for (label, d, o), out in zip(cases, decode(specs)):
+        assert out.status == 0 and out.data.tobytes() == d.tobytes() and np.array_equal(out.offsets[: o.size], o), label
+
+
+def test_byte_array_encoders_too_small_and_fixed_len():
+    P = pkg()
+    rng = np.random.default_rng(61)
+    data, offs = O._flatten(_strings(rng, "urls", 3000))
+    for enc, want in ((P.ENC.PLAIN, data.size + 4 * 3000), (P.ENC.DELTA_LENGTH_BYTE_ARRAY, len(O.dlba_encode(data=data, offsets=offs))),
+                      (P.ENC.DELTA_BYTE_ARRAY, len(O.dba_encode(data=data, offsets=offs)))):
+        bound = int(P.lib().pqd_encode_bound_byte_array(enc, 3000, data.size))
+        assert bound >= want
+        for short in (1, 40, want - 100, want):  # by how much the destination is too small: the size to come back with
+            status, arg, page, raw = _encode([(enc, P.KIND.BYTE_ARRAY, data, 0, offs)], dst_slack=want - short - bound)[0]
+            assert (status, arg, page) == (P.STATUS.DST_TOO_SMALL, want, b""), (enc, short, status, arg)
+    # FIXED_LEN_BYTE_ARRAY through DELTA_BYTE_ARRAY (byte_array.go:76-122)
+    for size in (1, 5, 16, 100):
+        for n in (0, 1, 200, 3000):
+            v = np.repeat(rng.integers(0, 256, size=(n // 4 + 1) * size, dtype=np.uint8).reshape(-1, size), 4, axis=0)[:n].copy()
+            v[:, -1] = rng.integers(0, 256, size=n)
+            flat = v.reshape(-1)
+            want = bytes(O.dba_encode(data=flat, offsets=np.arange(n + 1, dtype=np.uint32) * size))
+            status, arg, page, raw = _encode([(P.ENC.DELTA_BYTE_ARRAY, P.KIND.FIXED_LEN_BYTE_ARRAY, flat, size)])[0]
+            assert status == 0 and page == want, (size, n, status, arg)
+    # through the host entry point a cgo binding calls
+    import ctypes as C
+    L = P.lib()
+    for enc, want in ((P.ENC.PLAIN, None), (P.ENC.DELTA_LENGTH_BYTE_ARRAY, bytes(O.dlba_encode(data=data, offsets=offs))),
+                      (P.ENC.DELTA_BYTE_ARRAY, bytes(O.dba_encode(data=data, offsets=offs)))):
+        cap = int(L.pqd_encode_bound_byte_array(enc, 3000, data.size))
+        dst = np.zeros(cap, np.uint8)
+        n_out, arg = C.c_uint64(0), C.c_int64(0)
+        rc = L.pqd_encode_byte_array(ctx().handle, enc, P.KIND.BYTE_ARRAY, 0, data.ctypes.data, data.size, offs.ctypes.data, 3000, dst.ctypes.data, cap,
+                                     C.byref(n_out), C.byref(arg))
+        assert rc == 0
+        if want is not None:
+            assert dst[: n_out.value].tobytes() == want
+        else:
+            assert n_out.value == data.size + 4 * 3000
+
+
+@pytest.mark.parametrize("np_dtype,kind_name,unsigned", [(np.int32, "INT32", 0), (np.int64, "INT64", 0), (np.uint32, "INT32", 1), (np.uint64, "INT64", 1),
+                                                         (np.float32, "FLOAT", 0), (np.float64, "DOUBLE", 0)])
+def test_page_bounds(np_dtype, kind_name, unsigned):
+    """boundsInt32 ... boundsFloat64 (page_bounds_purego.go:9-107): min and max by the loop's comparisons."""
+    import torch
+    P = pkg()
+    L = P.lib()
+    rng = np.random.default_rng(70)
+    kind = getattr(P.KIND, kind_name)
+    ws = torch.zeros(64 << 10, dtype=torch.uint8, device="cuda")
+    out = torch.zeros(2, dtype=torch.int64, device="cuda")
+    st = torch.zeros(2, dtype=torch.int64, device="cuda")
+
+    def reference(v):
+        if v.size == 0:
+            return np.zeros(2, np_dtype)
+        lo = hi = v[0]
+        for x in v[1:]:
+            if x < lo:
+                lo = x
+            if x > hi:
+                hi = x
+        return np.array([lo, hi], np_dtype)
+
+    cases = [np.zeros(0, np_dtype)]
+    for n in (1, 2, 100, 2049, 100003):
+        if np.issubdtype(np_dtype, np.floating):
+            v = rng.standard_normal(n).astype(np_dtype)
+            cases.append(v)
+            w = v.copy(); w[rng.integers(0, n, size=max(1, n // 10))] = np.nan; w[0] = 1.5
+            cases.append(w)                       # NaNs inside never win
+            z = v.copy(); z[0] = np.nan
+            cases.append(z)                       # a NaN in front stays
+            cases.append(np.where(rng.integers(0, 2, size=n) == 1, np_dtype(0.0), np_dtype(-0.0)).astype(np_dtype))  # +0 and -0: the first stays
+        else:
+            info = np.iinfo(np_dtype)
+            cases.append(rng.integers(info.min, info.max, size=n, dtype=np_dtype, endpoint=True))
+            cases.append(np.full(n, info.max, np_dtype))
+    for v in cases:
+        t = torch.from_numpy(v.view(np.int32 if v.itemsize == 4 else np.int64).copy()).cuda() if v.size else torch.zeros(1, dtype=torch.int64, device="cuda")
+        rc = L.pqd_page_bounds_device(ctx().handle, kind, unsigned, t.data_ptr(), v.size, out.data_ptr(), ws.data_ptr(), ws.numel(), st.data_ptr(), None)
+        torch.cuda.synchronize()
+        assert rc == 0 and st.tolist() == [0, 0]
+        got = out.cpu().numpy().view(np.uint8)[: 2 * v.itemsize].view(np_dtype)
+        want = reference(v[: min(v.size, 3000)]) if v.size <= 3000 else np.array([np.nanmin(v) if v[0] == v[0] else v[0], np.nanmax(v) if v[0] == v[0] else v[0]], np_dtype)
+        assert got.tobytes() == want.tobytes() or (v.size > 3000 and np.array_equal(got, want)), (v.size, got, want)
+
+
+def test_encode_methods_of_the_codec_objects_for_levels_booleans_and_byte_arrays():
+    """The host entry points a cgo binding calls (pqd_encode_values, pqd_encode_byte_array) behind the mirror of
+    encoding.Encoding's Encode methods (encoding/encoding.go:29-41)."""
+    pkg()
+    from parquet_go_amd import encoding as E
+    rng = np.random.default_rng(80)
+    lv = np.repeat(rng.integers(0, 4, size=700, dtype=np.uint8), rng.integers(1, 30, size=700))
+    assert E.RLE(2).EncodeLevels(None, lv) == bytes(O.rle_encode_levels(lv, 2))
+    with pytest.raises(E.EncodingError):
+        E.RLE(9).EncodeLevels(None, lv)
+    bits = np.repeat(rng.choice(np.array([0, 0xFF, 0x3C], np.uint8), size=900), rng.integers(1, 9, size=900))
+    assert E.RLE().EncodeBoolean(None, bits) == bytes(O.rle_encode_boolean(bits))
+    idx = rng.integers(0, 1 << 11, size=5001, dtype=np.int32)
+    assert E.RLE(11).EncodeInt32(None, idx) == bytes(O.rle_encode_int32(idx, 11))
+    data, offs = O._flatten(_strings(rng, "urls", 2500))
+    assert E.DeltaLengthByteArray().EncodeByteArray(None, data, offs) == bytes(O.dlba_encode(data=data, offsets=offs))
+    assert E.DeltaByteArray().EncodeByteArray(None, data, offs) == bytes(O.dba_encode(data=data, offsets=offs))
+    assert E.Plain().EncodeByteArray(None, data, offs) == bytes(O.plain_encode_byte_array(_split(data, offs)))
+    assert E.DeltaLengthByteArray().EncodeByteArray(None, b"", None) == b""
+    fl = rng.integers(0, 4, size=16 * 999, dtype=np.uint8)
+    assert E.DeltaByteArray().EncodeFixedLenByteArray(None, fl, 16) == bytes(O.dba_encode(data=fl, offsets=np.arange(1000, dtype=np.uint32) * 16))
+    with pytest.raises(E.ErrInvalidArgument):
+        E.DeltaByteArray().EncodeFixedLenByteArray(None, fl[:-1], 16)
+    # and back
+    v, o = E.DeltaByteArray().DecodeByteArray(None, E.DeltaByteArray().EncodeByteArray(None, data, offs), None)
+    assert v.tobytes() == data.tobytes() and np.array_equal(o, offs)
+
+
+def _split(data, offs):
+    b = data.tobytes()
+    return [b[int(offs[i]): int(offs[i + 1])] for i in range(len(offs) - 1)]
