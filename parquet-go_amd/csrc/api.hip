@@ -61,6 +61,8 @@ struct pqd_batch {
     hipEvent_t fork = nullptr, join[3] = {nullptr, nullptr, nullptr};
     // generic tile grids for the element-parallel families
     uint64_t max_src[N_FAMILIES] = {0}; // longest src of each family, sizes the tile grids
+    uint32_t rle_page_small = 0;        // FAM_RLE_PAGE: the first so many items of the list are short pages (a wavefront each)
+    uint32_t* d_page_retry = nullptr;   // FAM_RLE_PAGE: a word the page kernel raises to the launch's number when it leaves a page to the retry kernel
     uint64_t dict_bytes_max_values = 0; // most values a page looked up in a byte dictionary may hold
     uint64_t dba_max_values = 0; // most values a DELTA_BYTE_ARRAY page of the batch is expected to hold
     uint64_t flat_blocks[N_FAMILIES] = {0}; // DELTA families decoded tile by tile: most blocks a page may hold (0: not used)
@@ -287,6 +289,9 @@ int pqd_ctx_create(int device, pqd_ctx** out) {
     // them take the page-per-workgroup kernel, otherwise those of up to RLE_PAGE_MAX_STEPS steps do
     const char* rp = getenv("PQD_RLE_PAGE");
     ctx->rle_page = rp != nullptr && (rp[0] == '0' || rp[0] == '2') ? rp[0] - '0' : 1;
+    // level pages of at most this many steps of 2048 values are decoded by one wavefront each, longer ones by four (0: all by four)
+    const char* rpw = getenv("PQD_RLE_PAGE_WAVE_STEPS");
+    ctx->rle_page_wave_steps = rpw != nullptr ? (uint32_t)strtoul(rpw, nullptr, 10) : 0; // (measured: four wavefronts are quicker at every size)
     ctx->plain_tiled = tiled != nullptr && (tiled[0] == '0' || tiled[0] == '1') ? tiled[0] - '0' : 2;
     // with this context's device current: where this GPU keeps the static workspace
     ctx->levels_scratch = nullptr;
@@ -565,6 +570,13 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
         rle_prefix[g].push_back(b->rle_tiles[g]);
         if (b->rle_tiles[g] > 0x7fffffffull) { delete b; return PQD_ERR_INVALID_ARGUMENT; }
     }
+    {
+        // level pages a wavefront takes by itself come first in their family's list, those four wavefronts share behind them
+        // (nothing else goes by a page's place in this list: the page kernels use no tile prefix)
+        std::vector<uint32_t>& lp = b->fam[FAM_RLE_PAGE].items;
+        const uint32_t small = ctx->rle_page_wave_steps;
+        b->rle_page_small = (uint32_t)(std::stable_partition(lp.begin(), lp.end(), [&](uint32_t k) { return b->items[k].n_steps <= small; }) - lp.begin());
+    }
 
     // ---- long RLE pages of a batch with few of them: indexed chunk by chunk, by many workgroups each ----
     // (a batch with many RLE pages keeps the chip busy with one wavefront per page; a page that is
@@ -636,6 +648,7 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_items = carve(n_items * sizeof(DevPage));
     const size_t o_results = carve(n_items * sizeof(DevResult));
+    const size_t o_page_retry = carve(sizeof(uint32_t)); // the last launch in which a level page was left to the retry kernel (uploaded as 0)
     size_t o_fam[N_FAMILIES];
     for (int f = 0; f < N_FAMILIES; f++) o_fam[f] = carve(b->fam[f].items.size() * sizeof(uint32_t));
     size_t o_rle_prefix[RLE_GRIDS], o_rle_tile_item[RLE_GRIDS];
@@ -715,6 +728,7 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
     uint8_t* a = static_cast<uint8_t*>(b->arena);
     b->d_items = reinterpret_cast<DevPage*>(a + o_items);
     b->d_results = reinterpret_cast<DevResult*>(a + o_results);
+    b->d_page_retry = reinterpret_cast<uint32_t*>(a + o_page_retry);
     for (int g = 0; g < RLE_GRIDS; g++) {
         b->d_rle_tile_prefix[g] = reinterpret_cast<uint64_t*>(a + o_rle_prefix[g]);
         b->d_rle_tile_item[g] = with_tile_item[g] ? reinterpret_cast<uint32_t*>(a + o_rle_tile_item[g]) : nullptr;
@@ -849,7 +863,7 @@ int pqd_batch_launch(pqd_batch* b, void* hip_stream) {
                                 RLE_FAMILY[g] == FAM_RLE_LDS8 ? 8 : 4, b->lds_plan[g], b->d_lds_wg_item[g], b->d_lds_seg_last[g], b->ck.pk_flag,
                                 b->launches, s_rle);
         else if (RLE_FAMILY[g] == FAM_RLE_PAGE)
-            launch_rle_pages(b->d_items, b->d_results, f.dev, (uint32_t)f.items.size(), s_rle);
+            launch_rle_pages(b->d_items, b->d_results, f.dev, (uint32_t)f.items.size(), b->rle_page_small, b->d_page_retry, b->launches, s_rle);
         else
             launch_rle_expand(b->d_items, b->d_results, f.dev, (uint32_t)f.items.size(), b->d_rle_tile_prefix[g], b->d_rle_tile_item[g],
                               b->rle_tiles[g], RLE_FAMILY[g], s_rle);

@@ -1106,6 +1106,7 @@ __device__ __forceinline__ void expand_runs_bytes(const u32x4* tab, uint32_t nr,
     }
 }
 
+template <int NW = ET / 64>
 __device__ __forceinline__ void page_expand(const u32x4* tab, uint32_t nr, const uint32_t* win, int64_t base, const DevPage& pg, uint32_t G0,
                                    uint32_t G1, uint32_t bw);
 
@@ -1289,17 +1290,18 @@ __global__ __launch_bounds__(ET) __attribute__((amdgpu_waves_per_eu(FAMILY == FA
 // and the bytes written are the same on every path.
 
 constexpr uint32_t PW_WIN = 4096;                 // bytes of the page resident at a time
-constexpr uint32_t PW_HDRS = ET;                  // headers followed per round: one per thread
+// (headers followed per round: one per thread of the workgroup)
 constexpr uint32_t PW_SLACK = 32;                 // LDS bytes behind the window that reads may touch
 constexpr uint64_t PAGE_RETRY = 0x5041474552455452ull; // DevResult::aux of a page rle_page_kernel left to the retry kernel
 static_assert(PW_WIN % ET == 0, "a whole number of positions per thread");
 
+template <int T>
 struct PageShared {
     uint32_t win[(GROUP_STAGE_PAD + PW_WIN + PW_SLACK) / 4];
     uint16_t adv[PW_WIN];                         // per position of the window: bytes to the next header, 0: none
-    uint16_t hdr[PW_HDRS];                        // positions (in the window) of the headers the chain holds
-    u32x4 tab[PW_HDRS + 1];                       // the round's runs (Run layout; in_off counts from the page's first byte)
-    uint64_t wsum[ET / 64];
+    uint16_t hdr[T];                              // positions (in the window) of the headers the chain holds
+    u32x4 tab[T + 1];                             // the round's runs (Run layout; in_off counts from the page's first byte)
+    uint64_t wsum[T / 64];
     // the walk, between rounds.  Positions count from the 16-byte boundary at or before the page's first byte.
     uint32_t pos;                                 // next header, or next group of the bit-packed run in progress
     uint32_t pending;                             // groups of eight values that run still holds
@@ -1389,9 +1391,12 @@ __device__ inline u32x4 page_unpack16(const uint32_t* win, uint32_t e_y, int64_t
 // splat or unpacks its sixteen fields without looking anything up; otherwise every lane finds
 // the run of its piece in the table, and a piece that meets several runs, or the ragged ends of a
 // stretch, goes value by value.
+constexpr uint32_t PAGE_FEW_RUNS = 8; // up to so many runs behind the first that meet 64 pieces are counted out of registers
+
+template <int NW>
 __device__ __forceinline__ void page_expand(const u32x4* tab, uint32_t nr, const uint32_t* win, int64_t base, const DevPage& pg, uint32_t G0,
                                    uint32_t G1, uint32_t bw) {
-    const uint32_t lane = threadIdx.x & 63, wave = pw_uniform(threadIdx.x >> 6);
+    const uint32_t lane = threadIdx.x & 63, wave = NW == 1 ? 0u : pw_uniform(threadIdx.x >> 6); // NW wavefronts share the pieces
     gptr<uint8_t> dst = as_global(pg.dst);
     const uint32_t a = (uint32_t)((uintptr_t)pg.dst & 15); // piece c holds the values [16 c - a, 16 c - a + 16)
     for (uint32_t rb = 0; rb < nr; rb += 64) {
@@ -1403,7 +1408,7 @@ __device__ __forceinline__ void page_expand(const u32x4* tab, uint32_t nr, const
         const uint32_t B1 = last_end < G1 ? last_end : G1; // this stretch of runs holds [B0, B1)
         if (B1 <= B0) break;
         const uint32_t c_lo = (B0 + a) >> 4, c_hi = (B1 + a + 15) >> 4;
-        for (uint32_t c0 = c_lo + wave * 64; c0 < c_hi; c0 += (ET / 64) * 64) {
+        for (uint32_t c0 = c_lo + wave * 64; c0 < c_hi; c0 += NW * 64) {
             const uint32_t c1 = c0 + 64 < c_hi ? c0 + 64 : c_hi;
             const uint32_t q_lo = c0 * 16 > B0 + a ? c0 * 16 - a : B0; // first value of these pieces inside the stretch
             const unsigned long long le = __ballot(mine.x <= q_lo);
@@ -1424,13 +1429,21 @@ __device__ __forceinline__ void page_expand(const u32x4* tab, uint32_t nr, const
                 *(gptr<u32x4>)(dst + P) = v;
                 continue;
             }
-            if (c >= c1) continue;
             // ---- the lane's own piece: [p0, p1) of it lie inside the stretch ----
-            const int64_t Ps = (int64_t)c * 16 - a;
+            const bool live = c < c1;
+            const int64_t Ps = (int64_t)(live ? c : c0) * 16 - a;
             const uint32_t p0 = Ps < (int64_t)B0 ? B0 : (uint32_t)Ps, p1 = Ps + 16 > (int64_t)B1 ? B1 : (uint32_t)(Ps + 16);
-            if (p1 <= p0) continue;
+            // Which run holds the piece's first value: counted over the runs that meet these 64 pieces, uniformly, out of
+            // the registers (a lane walking the table in LDS pays a dependent round trip per run it passes).
+            const uint32_t q_hi = c1 * 16 - a < B1 ? c1 * 16 - a : B1;
+            const uint32_t r_last = (uint32_t)__popcll(__ballot(mine.x < q_hi)) - 1; // (lanes without a run hold 0xffffffff)
             uint32_t rl = rb + r;
-            while (rl + 1 < rb + nb && tab[rl + 1].x <= p0) rl++;
+            if (r_last - r <= PAGE_FEW_RUNS) {
+                for (uint32_t k = r + 1; k <= r_last; k++) rl += (uint32_t)__builtin_amdgcn_readlane((int)mine.x, (int)k) <= p0 ? 1u : 0u;
+            } else {
+                while (rl + 1 < rb + nb && tab[rl + 1].x <= p0) rl++;
+            }
+            if (!live || p1 <= p0) continue;
             // what each run that meets the piece puts into its sixteen bytes, merged under byte masks
             u32x4 acc = u32x4{0, 0, 0, 0};
             for (uint32_t q = p0;;) {
@@ -1470,24 +1483,30 @@ __device__ __forceinline__ void page_expand(const u32x4* tab, uint32_t nr, const
 // in sh.hdr.  One wavefront; everything but the registers of distances and positions is uniform.
 // The distances of the 64 positions around the walk's position sit in one register (a lane
 // each): hops inside that stretch are a v_readlane away, a hop out of it costs one LDS read.
-__device__ inline void page_chase(PageShared& sh, uint32_t cur, uint32_t w_lo, uint32_t w_hi, uint32_t end) {
+template <int T>
+__device__ inline void page_chase(PageShared<T>& sh, uint32_t cur, uint32_t w_lo, uint32_t w_hi, uint32_t end) {
+    constexpr uint32_t PW_HDRS = T;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t size = w_hi - w_lo;
     uint32_t h = 0, n = 0;
-    bool zero = false, full = false;
-    while (!zero && !full && cur < size) {
-        const uint32_t seg = cur >> 6;
-        const uint32_t av = sh.adv[seg * 64 + lane]; // (positions at or behind the window's last byte are never looked at)
-        while ((cur >> 6) == seg && cur < size) {
-            const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)av, (int)(cur & 63));
-            if (d == 0) { zero = true; break; }
-            if (n == PW_HDRS) { full = true; break; }
-            h = lane == (n & 63) ? cur : h;
-            n++;
-            cur += d;
-            if ((n & 63) == 0) sh.hdr[n - 64 + lane] = (uint16_t)h;
+    bool zero = false;
+    cur = pw_uniform(cur);
+    __builtin_amdgcn_s_setprio(3); // the workgroup's other wavefronts wait for this walk: it goes first on its SIMD
+    // One loop, few branches: a taken branch costs this lone instruction stream more than the arithmetic of a hop.
+    uint32_t seg = 0xffffffffu, av = 0;
+    while (cur < size) {
+        if ((cur >> 6) != seg) { // the hop left the 64 positions held in `av`: one LDS read
+            seg = cur >> 6;
+            av = sh.adv[seg * 64 + lane]; // (positions at or behind the window's last byte are never looked at)
         }
+        const uint32_t d = (uint32_t)__builtin_amdgcn_readlane((int)av, (int)(cur & 63));
+        if ((d == 0) | (n == PW_HDRS)) { zero = d == 0; break; }
+        h = lane == (n & 63) ? cur : h;
+        n++;
+        cur += d;
+        if ((n & 63) == 0) sh.hdr[n - 64 + lane] = (uint16_t)h;
     }
+    __builtin_amdgcn_s_setprio(0);
     if (n & 63) sh.hdr[(n & ~63u) + lane] = (uint16_t)h;
     const uint32_t p = w_lo + cur;
     uint32_t reason = 0; // 0: the next round goes on from p, 1: p is the page's end, 2: p holds nothing the fast path takes
@@ -1496,10 +1515,14 @@ __device__ inline void page_chase(PageShared& sh, uint32_t cur, uint32_t w_lo, u
     if (lane == 0) { sh.n_hdr = n; sh.cur_end = p; sh.reason = reason; }
 }
 
-__global__ __launch_bounds__(ET) __attribute__((amdgpu_waves_per_eu(8, 8))) void rle_page_kernel(const DevPage* __restrict__ pages,
-                                                                                                 DevResult* __restrict__ results,
-                                                                                                 const uint32_t* __restrict__ items) {
-    __shared__ PageShared sh;
+// T threads take a page: 256 (four wavefronts share the expansion: long pages), or 64 -- short pages are a chain of
+// dependent steps (descriptor, window, distances, walk, table), and a wavefront that has a SIMD nearly to itself goes
+// through them several times faster than four that share theirs with twenty-eight others and meet at barriers.
+template <int T>
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T == 256 ? 8 : 2, 8))) void rle_page_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                     const uint32_t* __restrict__ items, uint32_t* __restrict__ retry_word, uint32_t launch) {
+    constexpr uint32_t ET = T; // (shadows the file's workgroup size inside this kernel)
+    __shared__ PageShared<T> sh;
 #ifdef PQD_PAGE_TIMING2
     const uint64_t t_entry = __builtin_readcyclecounter();
 #endif
@@ -1507,13 +1530,20 @@ __global__ __launch_bounds__(ET) __attribute__((amdgpu_waves_per_eu(8, 8))) void
     const DevPage& pg = pages[item];
     DevResult* res = &results[item];
     const uint32_t tid = threadIdx.x, wave = pw_uniform(tid >> 6), lane = tid & 63;
+    // (everything the kernel wants of the descriptor is asked for at once, with no branch in between: a test per field
+    // would be half a dozen trips to memory one after the other before the first byte of the page is on its way)
     const uint32_t bw = (uint32_t)pg.bit_width;
-    const bool dense = pg.kind == PQD_KIND_LEVELS && pg.encoding == PQD_ENC_RLE && pg.elem_width == 1 && pg.dst_stride <= 1 && !pg.fused;
-    if (dense && bw >= 1 && bw <= 8 && pg.src_len <= 0x7ff00000ull) {
-        const uint32_t mis = (uint32_t)((uintptr_t)pg.src & 15);
-        gptr<const uint8_t> base = as_global(pg.src) - mis;
-        const uint32_t end = mis + (uint32_t)pg.src_len;
-        const uint64_t limit64 = pg.num_values >= 0 && (uint64_t)pg.num_values < pg.dst_cap ? (uint64_t)pg.num_values : pg.dst_cap;
+    const int32_t d_kind = pg.kind, d_enc = pg.encoding, d_stride = pg.dst_stride;
+    const uint32_t d_elem = pg.elem_width, d_fused = pg.fused;
+    const uint8_t* const d_src = pg.src;
+    const uint64_t d_src_len = pg.src_len, d_cap = pg.dst_cap;
+    const int64_t d_num = pg.num_values;
+    const bool dense = (d_kind == PQD_KIND_LEVELS) & (d_enc == PQD_ENC_RLE) & (d_elem == 1) & (d_stride <= 1) & (d_fused == 0);
+    if (dense & (bw >= 1) & (bw <= 8) & (d_src_len <= 0x7ff00000ull)) {
+        const uint32_t mis = (uint32_t)((uintptr_t)d_src & 15);
+        gptr<const uint8_t> base = as_global(d_src) - mis;
+        const uint32_t end = mis + (uint32_t)d_src_len;
+        const uint64_t limit64 = d_num >= 0 && (uint64_t)d_num < d_cap ? (uint64_t)d_num : d_cap;
         const uint32_t limit = limit64 > MAX_TOTAL ? MAX_TOTAL : (uint32_t)limit64; // values that may be written
         if (tid == 0) { sh.pos = mis; sh.pending = 0; sh.total = 0; sh.state = 0; sh.n_runs = 0; }
         pw_barrier();
@@ -1617,7 +1647,7 @@ __global__ __launch_bounds__(ET) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             if (state == 2) break;
             // ---- D: the values ----
             const uint32_t G1 = (uint32_t)G1_64;
-            if (G0 < limit && G1 > G0) page_expand(sh.tab, nr, sh.win, (int64_t)w_lo - (int64_t)mis, pg, G0, G1 < limit ? G1 : limit, bw);
+            if (G0 < limit && G1 > G0) page_expand<T / 64>(sh.tab, nr, sh.win, (int64_t)w_lo - (int64_t)mis, pg, G0, G1 < limit ? G1 : limit, bw);
             if (state == 1) break;
             pw_barrier(); // the window and the table are rewritten
             PQD_TICK(t_exp)
@@ -1650,8 +1680,12 @@ __global__ __launch_bounds__(ET) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             return;
         }
     }
-    // ---- everything else is left to rle_page_retry_kernel ----
-    if (tid == 0) res->aux = PAGE_RETRY;
+    // ---- everything else is left to rle_page_retry_kernel: the page is marked, and so is the launch (launch numbers
+    // only grow, so the word needs no clearing between launches: the retry kernel compares it with its own) ----
+    if (tid == 0) {
+        res->aux = PAGE_RETRY;
+        atomicMax(retry_word, launch);
+    }
 }
 
 // The pages rle_page_kernel gave up on: the page's run table by one wavefront, then tile by tile,
@@ -1659,10 +1693,12 @@ __global__ __launch_bounds__(ET) __attribute__((amdgpu_waves_per_eu(8, 8))) void
 // Usually there are none, so the grid is small: workgroup b looks at the pages b, b + grid, ...,
 // a thread per page, and takes the flagged ones in turn.
 __global__ __launch_bounds__(ET) void rle_page_retry_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
-                                                            const uint32_t* __restrict__ items, uint32_t n_items) {
+                                                            const uint32_t* __restrict__ items, uint32_t n_items,
+                                                            const uint32_t* __restrict__ retry_word, uint32_t launch) {
     __shared__ EShared sh;
     __shared__ ICtl ctl;
     __shared__ unsigned long long flagged[ET / 64];
+    if (*as_global(retry_word) != launch) return; // no page of this launch was left over: the usual case, one load and out
     for (uint32_t k0 = blockIdx.x; k0 < n_items; k0 += gridDim.x * ET) {
         const uint32_t k = k0 + threadIdx.x * gridDim.x;
         const bool retry = k < n_items && as_global((const DevResult*)&results[items[k]])->aux == PAGE_RETRY;
@@ -2669,10 +2705,14 @@ if (plan.slices > 1) {
 #undef PQD_LDS_LAUNCH
 }
 
-void launch_rle_pages(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, hipStream_t stream) {
+void launch_rle_pages(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint32_t n_small, uint32_t* retry_word,
+                      uint32_t launch, hipStream_t stream) {
     if (n_items == 0) return;
-    hipLaunchKernelGGL(rle_page_kernel, dim3(n_items), dim3(ET), 0, stream, pages, results, items);
-    hipLaunchKernelGGL(rle_page_retry_kernel, dim3(n_items < 256 ? n_items : 256), dim3(ET), 0, stream, pages, results, items, n_items);
+    if (n_small > n_items) n_small = n_items;
+    if (n_small > 0) hipLaunchKernelGGL(rle_page_kernel<64>, dim3(n_small), dim3(64), 0, stream, pages, results, items, retry_word, launch);
+    if (n_small < n_items)
+        hipLaunchKernelGGL(rle_page_kernel<256>, dim3(n_items - n_small), dim3(256), 0, stream, pages, results, items + n_small, retry_word, launch);
+    hipLaunchKernelGGL(rle_page_retry_kernel, dim3(n_items < 256 ? n_items : 256), dim3(ET), 0, stream, pages, results, items, n_items, retry_word, launch);
 }
 
 void launch_rle_index(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, const uint32_t* pk_flag,
