@@ -1032,13 +1032,11 @@ __device__ inline void ba_copy64(gptr<const uint8_t> src, gptr<uint8_t> dst, uin
     const uint32_t align = (uint32_t)((uintptr_t)(dst + to0) & 15);
     if (lane < cnt) {
         uint8_t* q = img + align + (uint32_t)(to - to0);
-        if (head) { q[0] = (uint8_t)len; q[1] = (uint8_t)(len >> 8); q[2] = (uint8_t)(len >> 16); q[3] = (uint8_t)(len >> 24); q += 4; }
+        // (LDS takes a dword at any address on this chip)
+        if (head) { *reinterpret_cast<u32_a1e*>(q) = len; q += 4; }
         gptr<const uint8_t> s = src + from;
         uint32_t b = 0;
-        for (; b + 4 <= len; b += 4) {
-            const uint32_t x = *(gptr<const u32_a1e>)(s + b);
-            q[b] = (uint8_t)x; q[b + 1] = (uint8_t)(x >> 8); q[b + 2] = (uint8_t)(x >> 16); q[b + 3] = (uint8_t)(x >> 24);
-        }
+        for (; b + 4 <= len; b += 4) *reinterpret_cast<u32_a1e*>(q + b) = *(gptr<const u32_a1e>)(s + b);
         for (; b < len; b++) q[b] = s[b];
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // one wavefront: its LDS operations execute in order
