@@ -151,3 +151,62 @@ func (s *Stream) Download(dst []byte, src DevicePtr) error {
 	return hipError("hipMemcpyAsync", C.hipMemcpyAsync(unsafe.Pointer(unsafe.SliceData(dst)), unsafe.Pointer(uintptr(src)),
 		C.size_t(len(dst)), C.hipMemcpyDeviceToHost, s.h))
 }
+
+// HostSlab is page-locked host memory that the context knows about: the per-page codec methods
+// (DecodeInt64, DecodeByteArray, ...) copy straight out of and into slices that lie inside it and
+// skip their own staging copies.  A reader's buffer pool cuts its page and value buffers from one.
+type HostSlab struct {
+	ctx        *Context
+	ptr        unsafe.Pointer
+	size       int
+	registered bool // page-locked in place (RegisterHostMemory) rather than allocated by the library
+}
+
+// NewHostSlab allocates size bytes of page-locked memory outside the Go heap (pqd_host_alloc).
+func (c *Context) NewHostSlab(size int) (*HostSlab, error) {
+	var p unsafe.Pointer
+	if st := C.pqd_host_alloc(c.handle(), C.uint64_t(size), &p); st != C.PQD_OK {
+		return nil, fmt.Errorf("pqd: page-locked host memory: %s: %w", statusName(st), ErrDevice)
+	}
+	return &HostSlab{ctx: c, ptr: p, size: size}, nil
+}
+
+// RegisterHostMemory page-locks memory the caller already holds (pqd_host_register).  The memory
+// must not move or be freed before Release: C memory or a pinned slice (runtime.Pinner), never a
+// plain Go slice.  Drivers that cannot lock user memory return ErrDevice.
+func (c *Context) RegisterHostMemory(mem []byte) (*HostSlab, error) {
+	if len(mem) == 0 {
+		return nil, fmt.Errorf("pqd: no memory to register: %w", ErrDevice)
+	}
+	p := unsafe.Pointer(unsafe.SliceData(mem))
+	if st := C.pqd_host_register(c.handle(), p, C.uint64_t(len(mem))); st != C.PQD_OK {
+		return nil, fmt.Errorf("pqd: page-locked host memory: %s: %w", statusName(st), ErrDevice)
+	}
+	return &HostSlab{ctx: c, ptr: p, size: len(mem), registered: true}, nil
+}
+
+// Bytes returns the slab as a slice, valid until Release.
+func (s *HostSlab) Bytes() []byte {
+	if s.ptr == nil {
+		return nil
+	}
+	return unsafe.Slice((*byte)(s.ptr), s.size)
+}
+
+// Release frees (or unlocks) the memory; no call that uses it may still be running.
+func (s *HostSlab) Release() error {
+	if s.ptr == nil {
+		return nil
+	}
+	var st C.int
+	if s.registered {
+		st = C.pqd_host_unregister(s.ctx.handle(), s.ptr)
+	} else {
+		st = C.pqd_host_free(s.ctx.handle(), s.ptr)
+	}
+	s.ptr, s.size = nil, 0
+	if st != C.PQD_OK {
+		return fmt.Errorf("pqd: releasing page-locked host memory: %s: %w", statusName(st), ErrDevice)
+	}
+	return nil
+}

@@ -267,6 +267,25 @@ int pqd_encode_batch(pqd_ctx* ctx, pqd_encode_page* pages, uint64_t n_pages, voi
 int pqd_encode_values(pqd_ctx* ctx, int encoding, int kind, int bit_width, const void* src, uint64_t n_values,
                       uint8_t* dst, uint64_t dst_cap, uint64_t* out_bytes, int64_t* status_arg);
 
+/*
+ * Host memory the copy engines may reach directly.  The per-method entry points above take plain host
+ * pointers, as the reference's codecs take Go slices (encoding/encoding.go:43-56), and move the bytes
+ * through pinned staging of their own -- for a page of 1 MiB those two memcpys are most of what a call
+ * costs.  A reader whose page buffers come from a pool (buffer.go:476-561, column.go:863-871) makes the
+ * pool's memory known once: calls whose src, dst or offsets lie inside a known range are copied from and to
+ * where they lie.  Two ways: pqd_host_register page-locks memory the caller already has (it returns
+ * PQD_ERR_DEVICE where the driver does not lock user memory, as under some virtual machines), and
+ * pqd_host_alloc hands out page-locked memory of the library's (for cgo: memory outside the Go heap, which
+ * the reference's buffer pool can wrap as it wraps its own slabs).  The memory stays locked until
+ * pqd_host_unregister(ptr) / pqd_host_free(ptr) (the first byte of the range) or pqd_ctx_destroy; it must
+ * outlive every call that uses it.  With a known dst the whole of dst[0 .. dst_cap) may be overwritten, not
+ * only the out_bytes the call reports.
+ */
+int pqd_host_register(pqd_ctx* ctx, void* ptr, uint64_t bytes);
+int pqd_host_unregister(pqd_ctx* ctx, void* ptr);
+int pqd_host_alloc(pqd_ctx* ctx, uint64_t bytes, void** out);
+int pqd_host_free(pqd_ctx* ctx, void* ptr);
+
 /* One BYTE_ARRAY page, host pointers in and out: EncodeByteArray(dst, src, offsets) of plain.Encoding,
  * delta.LengthByteArrayEncoding and delta.ByteArrayEncoding (encoding/plain/plain.go:44-57,
  * encoding/delta/length_byte_array.go:20-35, encoding/delta/byte_array.go:26-74); `offsets` holds

@@ -167,6 +167,10 @@ SYMBOLS = {
     "pqd_dict_lookup_device": (_int, [_vp, _vp, _u64, C.c_uint32, _vp, _u64, _vp, _u64, _vp, _vp]),
     "pqd_dict_lookup_bytes_device": (_int, [_vp, C.c_int32, _vp, _vp, _u64, C.c_uint32, _vp, _u64, _vp, _u64, _vp, _u64, _vp, _vp]),
     "pqd_encode_bound": (_u64, [_int, _int, _int, _u64]),
+    "pqd_host_register": (_int, [_vp, _vp, _u64]),
+    "pqd_host_unregister": (_int, [_vp, _vp]),
+    "pqd_host_alloc": (_int, [_vp, _u64, C.POINTER(C.c_void_p)]),
+    "pqd_host_free": (_int, [_vp, _vp]),
     "pqd_encode_bound_byte_array": (_u64, [_int, _u64, _u64]),
     "pqd_encode_byte_array": (_int, [_vp, _int, _int, _int, _vp, _u64, _vp, _u64, _vp, _u64, _pu64, _pi64]),
     "pqd_encode_workspace_size": (_u64, [C.POINTER(EncodePage), _u64]),

@@ -314,6 +314,10 @@ void pqd_ctx_destroy(pqd_ctx* ctx) {
     if (ctx == nullptr) return;
     DeviceGuard guard(ctx->device);
     for (Workspace* ws : ctx->idle) { ws->release(); delete ws; }
+    for (const auto& r : ctx->registered) { // what the caller left registered or allocated
+        if (r.owned) (void)hipHostFree(reinterpret_cast<void*>(r.first));
+        else (void)hipHostUnregister(reinterpret_cast<void*>(r.first));
+    }
     for (hipStream_t st : ctx->side)
         if (st != nullptr) (void)hipStreamDestroy(st);
     delete ctx;

@@ -102,9 +102,13 @@ int decode_host(pqd_ctx* ctx, int encoding, int kind, int bit_width, const uint8
     if (!ws->reserve_io(total)) return PQD_ERR_DEVICE;
     uint8_t* d_io = static_cast<uint8_t*>(ws->d_io);
     uint8_t* h_io = static_cast<uint8_t*>(ws->h_io);
+    // Memory the caller has registered (pqd_host_register) is reached by the copy engines where it lies: no
+    // memcpy through the workspace's pinned staging, which for a page of 1 MiB is most of what a call costs the host.
+    const bool src_direct = ctx->host_registered(src, src_len);
+    const bool dst_direct = ctx->host_registered(dst, dst_cap);
     if (src_len) {
-        std::memcpy(h_io + o_src, src, src_len);
-        PQD_HIP(hipMemcpyAsync(d_io + o_src, h_io + o_src, src_len, hipMemcpyHostToDevice, ws->stream));
+        if (!src_direct) std::memcpy(h_io + o_src, src, src_len);
+        PQD_HIP(hipMemcpyAsync(d_io + o_src, src_direct ? src : h_io + o_src, src_len, hipMemcpyHostToDevice, ws->stream));
     }
     pqd_page p;
     std::memset(&p, 0, sizeof p);
@@ -120,22 +124,23 @@ int decode_host(pqd_ctx* ctx, int encoding, int kind, int bit_width, const uint8
     // Most pages fill the destination the caller sized for them: the values start back together with
     // the results, and only a page that came out shorter or failed is looked at again.
     const bool with_offsets = offsets != nullptr && kind == PQD_KIND_BYTE_ARRAY;
+    const bool off_direct = with_offsets && ctx->host_registered(offsets, offsets_cap * 4);
     if (rc == PQD_OK && dst_cap)
-        rc = hipMemcpyAsync(h_io + o_dst, d_io + o_dst, dst_cap, hipMemcpyDeviceToHost, ws->stream) == hipSuccess ? PQD_OK : PQD_ERR_DEVICE;
+        rc = hipMemcpyAsync(dst_direct ? dst : h_io + o_dst, d_io + o_dst, dst_cap, hipMemcpyDeviceToHost, ws->stream) == hipSuccess ? PQD_OK : PQD_ERR_DEVICE;
     if (rc == PQD_OK && with_offsets && offsets_cap)
-        rc = hipMemcpyAsync(h_io + o_off, d_io + o_off, offsets_cap * 4, hipMemcpyDeviceToHost, ws->stream) == hipSuccess ? PQD_OK : PQD_ERR_DEVICE;
+        rc = hipMemcpyAsync(off_direct ? (void*)offsets : (void*)(h_io + o_off), d_io + o_off, offsets_cap * 4, hipMemcpyDeviceToHost, ws->stream) == hipSuccess ? PQD_OK : PQD_ERR_DEVICE;
     if (rc == PQD_OK) rc = batch_finish_ws(b, ws, &p);
     else (void)hipStreamSynchronize(ws->stream);
     pqd_batch_destroy(b);
     if (rc != PQD_OK) return rc;
     if (status_arg) *status_arg = p.status_arg;
     const uint64_t nb = p.out_bytes < dst_cap ? p.out_bytes : dst_cap;
-    if (nb) std::memcpy(dst, h_io + o_dst, nb);
+    if (nb && !dst_direct) std::memcpy(dst, h_io + o_dst, nb);
     if (out_bytes) *out_bytes = nb;
     if (with_offsets) {
         uint64_t no = p.status == PQD_OK ? p.out_values + 1 : p.out_values;
         if (no > offsets_cap) no = offsets_cap;
-        if (no) std::memcpy(offsets, h_io + o_off, no * 4);
+        if (no && !off_direct) std::memcpy(offsets, h_io + o_off, no * 4);
         if (out_offsets) *out_offsets = no;
     }
     return p.status;
@@ -388,6 +393,59 @@ int pqd_encode_byte_array(pqd_ctx* ctx, int encoding, int kind, int type_length,
     }
     if (out_bytes) *out_bytes = p.status == PQD_OK ? p.out_bytes : 0;
     return p.status;
+}
+
+int pqd_host_register(pqd_ctx* ctx, void* ptr, uint64_t bytes) {
+    if (ctx == nullptr || ptr == nullptr || bytes == 0) return PQD_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return PQD_ERR_DEVICE;
+    if (hipHostRegister(ptr, bytes, hipHostRegisterDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return PQD_ERR_DEVICE;
+    }
+    std::lock_guard<std::mutex> lock(ctx->reg_mu);
+    ctx->registered.push_back({reinterpret_cast<uintptr_t>(ptr), bytes, false});
+    return PQD_OK;
+}
+
+int pqd_host_alloc(pqd_ctx* ctx, uint64_t bytes, void** out) {
+    if (ctx == nullptr || out == nullptr || bytes == 0) return PQD_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    DeviceGuard guard(ctx->device);
+    if (!guard.ok) return PQD_ERR_DEVICE;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return PQD_ERR_DEVICE;
+    }
+    std::lock_guard<std::mutex> lock(ctx->reg_mu);
+    ctx->registered.push_back({reinterpret_cast<uintptr_t>(p), bytes, true});
+    *out = p;
+    return PQD_OK;
+}
+
+// Takes the range that starts at ptr off the list; `owned` says which of the two calls put it there.
+static bool drop_host_range(pqd_ctx* ctx, void* ptr, bool owned) {
+    std::lock_guard<std::mutex> lock(ctx->reg_mu);
+    auto it = ctx->registered.begin();
+    while (it != ctx->registered.end() && !(it->first == reinterpret_cast<uintptr_t>(ptr) && it->owned == owned)) ++it;
+    if (it == ctx->registered.end()) return false;
+    ctx->registered.erase(it);
+    return true;
+}
+
+int pqd_host_free(pqd_ctx* ctx, void* ptr) {
+    if (ctx == nullptr || ptr == nullptr) return PQD_ERR_INVALID_ARGUMENT;
+    if (!drop_host_range(ctx, ptr, true)) return PQD_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(ctx->device);
+    return guard.ok && hipHostFree(ptr) == hipSuccess ? PQD_OK : PQD_ERR_DEVICE;
+}
+
+int pqd_host_unregister(pqd_ctx* ctx, void* ptr) {
+    if (ctx == nullptr || ptr == nullptr) return PQD_ERR_INVALID_ARGUMENT;
+    if (!drop_host_range(ctx, ptr, false)) return PQD_ERR_INVALID_ARGUMENT;
+    DeviceGuard guard(ctx->device);
+    return guard.ok && hipHostUnregister(ptr) == hipSuccess ? PQD_OK : PQD_ERR_DEVICE;
 }
 
 int pqd_can_decode_in_place(int encoding) {

@@ -34,6 +34,19 @@ struct pqd_ctx {
     std::mutex mu;                          // guards the list below
     std::vector<struct pqd::Workspace*> idle; // workspaces of the host entry points that no call is using
     void* levels_scratch; // this device's copy of the static workspace of pqd_optional_expand_noalloc (null: look-up failed)
+    // page-locked host memory the caller has registered (pqd_host_register) or taken from the library (pqd_host_alloc):
+    // the host entry points copy straight out of and into it
+    struct HostRange { uintptr_t first; uint64_t second; bool owned; }; // first byte, bytes, allocated by pqd_host_alloc
+    std::mutex reg_mu;
+    std::vector<HostRange> registered;
+    bool host_registered(const void* p, uint64_t bytes) {
+        if (p == nullptr || bytes == 0) return false;
+        std::lock_guard<std::mutex> lock(reg_mu);
+        const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+        for (const auto& r : registered)
+            if (a >= r.first && bytes <= r.second && a - r.first <= r.second - bytes) return true;
+        return false;
+    }
 };
 
 struct pqd_dict {

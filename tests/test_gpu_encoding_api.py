@@ -9,7 +9,7 @@ import pytest
 
 from oracle import pqoracle as O
 from tests import refdata as R
-from tests.gpu_util import pkg
+from tests.gpu_util import ctx, pkg
 
 pytestmark = pytest.mark.gpu
 
@@ -239,3 +239,66 @@ def test_dictionary_lookup_on_device_pointers():
                                       rows.data_ptr(), stride, st.data_ptr(), C.c_void_p(stream))
         torch.cuda.synchronize()
         assert rc == 0 and st.tolist() == [P.STATUS.INDEX_OUT_OF_BOUNDS, 777]
+
+
+@pytest.mark.parametrize("how", ["alloc", "register"])
+def test_page_locked_host_memory_is_copied_in_place(how):
+    """pqd_host_alloc / pqd_host_register: calls whose buffers lie in memory the library knows to be page-locked skip the
+    staging memcpys; results are the same as from pageable memory, for fixed-width values and for byte arrays with their
+    offsets.  Registration of user memory is refused by some drivers (virtual machines): that case is skipped, the
+    library's own allocation must always work."""
+    import ctypes as C
+    P = pkg()
+    L = P.lib()
+    H = ctx().handle
+    rng = np.random.default_rng(77)
+    v = np.cumsum(rng.integers(-1000, 100000, size=40000)).astype(np.int64)
+    page = np.frombuffer(bytes(O.delta_encode_int64(v)), np.uint8).copy()
+    strs = [bytes(rng.integers(97, 123, size=int(rng.integers(0, 30)), dtype=np.uint8)) for _ in range(5000)]
+    spage = np.frombuffer(bytes(O.dlba_encode(strs)), np.uint8).copy()
+    joined = b"".join(strs)
+    if how == "alloc":
+        got = C.c_void_p()
+        assert L.pqd_host_alloc(H, 1 << 20, C.byref(got)) == 0 and got.value
+        base = got.value
+        slab = np.frombuffer((C.c_uint8 * (1 << 20)).from_address(base), np.uint8)
+        release = L.pqd_host_free
+    else:
+        slab = np.zeros(1 << 20, np.uint8)
+        base = slab.ctypes.data
+        rc = L.pqd_host_register(H, C.c_void_p(base), C.c_uint64(slab.nbytes))
+        if rc == P.STATUS.DEVICE:
+            pytest.skip("this driver does not page-lock user memory (hipHostRegister refused)")
+        assert rc == 0
+        release = L.pqd_host_unregister
+    try:
+        src = slab[4096: 4096 + page.size]; src[:] = page
+        assert page.size < 120000
+        dst = slab[131072: 131072 + v.nbytes].view(np.int64)
+        nb, arg = C.c_uint64(0), C.c_int64(0)
+        # src and dst registered; then only dst; then only src
+        plain_dst = np.zeros(v.size, np.int64)
+        for s_arr, d_arr in ((src, dst), (page, dst), (src, plain_dst)):
+            d_arr[:] = 0
+            rc = L.pqd_decode_int64(H, P.ENC.DELTA_BINARY_PACKED, C.c_void_p(s_arr.ctypes.data), s_arr.size, C.c_void_p(d_arr.ctypes.data), d_arr.nbytes,
+                                    C.byref(nb), C.byref(arg))
+            assert rc == 0 and nb.value == v.nbytes and np.array_equal(d_arr, v)
+        # byte arrays: values and offsets into the slab
+        ssrc = slab[500000: 500000 + spage.size]; ssrc[:] = spage
+        sdst = slab[600000: 600000 + len(joined) + 64]
+        soff = slab[800000: 800000 + 4 * (len(strs) + 8)].view(np.uint32)
+        no = C.c_uint64(0)
+        rc = L.pqd_decode_byte_array(H, P.ENC.DELTA_LENGTH_BYTE_ARRAY, C.c_void_p(ssrc.ctypes.data), ssrc.size, C.c_void_p(sdst.ctypes.data), sdst.size,
+                                     C.c_void_p(soff.ctypes.data), soff.size, C.byref(nb), C.byref(no), C.byref(arg))
+        assert rc == 0 and nb.value == len(joined) and no.value == len(strs) + 1
+        assert sdst[: nb.value].tobytes() == joined
+        assert np.array_equal(soff[: no.value], np.concatenate([[0], np.cumsum([len(x) for x in strs])]).astype(np.uint32))
+        # a destination too small still says how much is needed
+        rc = L.pqd_decode_int64(H, P.ENC.DELTA_BINARY_PACKED, C.c_void_p(src.ctypes.data), src.size, C.c_void_p(dst.ctypes.data), 800, C.byref(nb), C.byref(arg))
+        assert (rc, arg.value) == (P.STATUS.DST_TOO_SMALL, v.nbytes)
+    finally:
+        del slab
+        assert release(H, C.c_void_p(base)) == 0
+    assert release(H, C.c_void_p(base)) == P.STATUS.INVALID_ARGUMENT  # not known any more
+    assert L.pqd_host_register(H, None, 10) == P.STATUS.INVALID_ARGUMENT
+    assert L.pqd_host_alloc(H, 0, C.byref(C.c_void_p())) == P.STATUS.INVALID_ARGUMENT

@@ -108,6 +108,57 @@ for threads in (1, 16):
     per_call("estimate DELTA_LENGTH_BYTE_ARRAY", estimate(pkg.ENC.DELTA_LENGTH_BYTE_ARRAY, dlba_page), str_bytes, threads)
     per_call("DELTA_BINARY_PACKED int64 8 KiB", fixed(L.pqd_decode_int64, pkg.ENC.DELTA_BINARY_PACKED, small_page, 1024, np.int64), 8192, threads)
 
+# The same calls with the caller's buffers in page-locked memory the library knows (pqd_host_alloc, or pqd_host_register
+# where the driver locks user memory): a reader's buffer pool.  Every thread's destination and the page bytes come out
+# of one slab.
+print("the same with the caller's buffers in page-locked memory of the library (pqd_host_alloc): copies go from and to it directly")
+SLAB_T = 16
+SLAB_BYTES = SLAB_T * (PAGE * 8 + 4096) + 4 * (1 << 20)
+_slab_at = C.c_void_p()
+assert L.pqd_host_alloc(H, C.c_uint64(SLAB_BYTES), C.byref(_slab_at)) == 0
+slab = np.frombuffer((C.c_uint8 * SLAB_BYTES).from_address(_slab_at.value), np.uint8)
+_at = [0]
+
+
+def from_slab(nbytes, dtype=np.uint8):
+    a = (_at[0] + 255) & ~255
+    _at[0] = a + nbytes
+    assert _at[0] <= slab.nbytes
+    return slab[a: a + nbytes].view(dtype)
+
+
+def reg_copy(page):
+    out = from_slab(page.size)
+    out[:] = page
+    return out
+
+
+def fixed_reg(fn, code, page, n_out, dtype, *pre):
+    dsts = [from_slab(n_out * np.dtype(dtype).itemsize, dtype) for _ in range(SLAB_T)]
+
+    def make(t):
+        dst = dsts[t]
+        nb, arg = C.c_uint64(0), C.c_int64(0)
+        args = (H, code) + pre + (_ptr(page), C.c_uint64(page.size), _ptr(dst), C.c_uint64(dst.nbytes), C.byref(nb), C.byref(arg))
+        return lambda keep=(dst, page): fn(*args)
+    return make
+
+
+r_delta, r_plain, r_rle = reg_copy(delta_page), reg_copy(plain_page), reg_copy(rle_page)
+_at_keep = _at[0]
+for threads in (1, 16):
+    _at[0] = _at_keep
+    per_call("DELTA_BINARY_PACKED int64 1 MiB", fixed_reg(L.pqd_decode_int64, pkg.ENC.DELTA_BINARY_PACKED, r_delta, PAGE, np.int64), PAGE * 8, threads)
+    _at[0] = _at_keep
+    per_call("PLAIN int64 1 MiB", fixed_reg(L.pqd_decode_int64, pkg.ENC.PLAIN, r_plain, PAGE, np.int64), PAGE * 8, threads)
+    _at[0] = _at_keep
+    per_call("RLE_DICTIONARY indexes 1 MiB", fixed_reg(L.pqd_decode_int32, pkg.ENC.RLE_DICTIONARY, r_rle, PAGE * 2, np.int32, 0), PAGE * 8, threads)
+_at[0] = _at_keep
+one = fixed_reg(L.pqd_decode_int64, pkg.ENC.DELTA_BINARY_PACKED, r_delta, PAGE, np.int64)(0)
+assert one() == 0
+del one, r_delta, r_plain, r_rle, slab
+assert L.pqd_host_free(H, _slab_at) == 0
+
 n = 16 << 20
 ts = 1_600_000_000_000_000_000 + np.cumsum(rng.integers(1_000_000, 1_004_096, size=n, dtype=np.int64))
 page = bench.delta_page_int64(ts)
