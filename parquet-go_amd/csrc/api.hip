@@ -292,6 +292,11 @@ int pqd_ctx_create(int device, pqd_ctx** out) {
     // level pages of at most this many steps of 2048 values are decoded by one wavefront each, longer ones by four (0: all by four)
     const char* rpw = getenv("PQD_RLE_PAGE_WAVE_STEPS");
     ctx->rle_page_wave_steps = rpw != nullptr ? (uint32_t)strtoul(rpw, nullptr, 10) : 0; // (measured: four wavefronts are quicker at every size)
+    // PQD_RLE_PAGE_THREADS: 256 or 1024 threads to a level page whatever the batch (tests, measurements); otherwise
+    // few pages get wide workgroups and many pages narrow ones
+    const char* rpt = getenv("PQD_RLE_PAGE_THREADS");
+    const uint32_t rpt_v = rpt != nullptr ? (uint32_t)strtoul(rpt, nullptr, 10) : 0;
+    ctx->rle_page_threads = rpt_v == 256 || rpt_v == 1024 ? rpt_v : 0;
     ctx->plain_tiled = tiled != nullptr && (tiled[0] == '0' || tiled[0] == '1') ? tiled[0] - '0' : 2;
     // with this context's device current: where this GPU keeps the static workspace
     ctx->levels_scratch = nullptr;
@@ -867,7 +872,7 @@ int pqd_batch_launch(pqd_batch* b, void* hip_stream) {
                                 RLE_FAMILY[g] == FAM_RLE_LDS8 ? 8 : 4, b->lds_plan[g], b->d_lds_wg_item[g], b->d_lds_seg_last[g], b->ck.pk_flag,
                                 b->launches, s_rle);
         else if (RLE_FAMILY[g] == FAM_RLE_PAGE)
-            launch_rle_pages(b->d_items, b->d_results, f.dev, (uint32_t)f.items.size(), b->rle_page_small, b->d_page_retry, b->launches, s_rle);
+            launch_rle_pages(b->d_items, b->d_results, f.dev, (uint32_t)f.items.size(), b->rle_page_small, b->ctx->rle_page_threads, b->d_page_retry, b->launches, s_rle);
         else
             launch_rle_expand(b->d_items, b->d_results, f.dev, (uint32_t)f.items.size(), b->d_rle_tile_prefix[g], b->d_rle_tile_item[g],
                               b->rle_tiles[g], RLE_FAMILY[g], s_rle);

@@ -30,6 +30,7 @@ struct pqd_ctx {
     uint64_t dict_slice_bytes;   // bytes of a slice (0: the default)
     int32_t plain_tiled;         // PLAIN byte arrays by many workgroups per page (0: one wavefront per page)
     int32_t rle_page;            // level pages by a workgroup each, index and expansion in one launch (0: never)
+    uint32_t rle_page_threads;    // threads of a level page's workgroup: 256 or 1024; 0: sized to the batch
     uint32_t rle_page_wave_steps; // such pages of at most this many steps are taken by a single wavefront
     std::mutex mu;                          // guards the list below
     std::vector<struct pqd::Workspace*> idle; // workspaces of the host entry points that no call is using
@@ -308,7 +309,8 @@ uint32_t rle_chunk_bytes();
 void launch_rle_chunked(const DevPage* pages, DevResult* results, const RleChunks& c, hipStream_t stream);
 void launch_rle_expand(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items,
                        const uint64_t* tile_prefix, const uint32_t* tile_item, uint64_t n_tiles, int32_t family, hipStream_t stream);
-void launch_rle_pages(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint32_t n_small, uint32_t* retry_word,
+void launch_rle_pages(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint32_t n_small, uint32_t threads,
+                      uint32_t* retry_word,
                       uint32_t launch, hipStream_t stream);
 
 // Dictionary pages through an LDS-resident dictionary (persistent workgroups).

@@ -1292,6 +1292,10 @@ __global__ __launch_bounds__(ET) __attribute__((amdgpu_waves_per_eu(FAMILY == FA
 constexpr uint32_t PW_WIN = 4096;                 // bytes of the page resident at a time
 // (headers followed per round: one per thread of the workgroup)
 constexpr uint32_t PW_SLACK = 32;                 // LDS bytes behind the window that reads may touch
+#ifndef PQD_PAGE_HOPS_LOG2
+#define PQD_PAGE_HOPS_LOG2 3
+#endif
+constexpr uint32_t PAGE_HOPS_LOG2 = PQD_PAGE_HOPS_LOG2;            // wide workgroups: the walk takes 2^3 headers per step (see page_chase_hops)
 constexpr uint64_t PAGE_RETRY = 0x5041474552455452ull; // DevResult::aux of a page rle_page_kernel left to the retry kernel
 static_assert(PW_WIN % ET == 0, "a whole number of positions per thread");
 
@@ -1302,6 +1306,10 @@ struct PageShared {
     uint16_t hdr[T];                              // positions (in the window) of the headers the chain holds
     u32x4 tab[T + 1];                             // the round's runs (Run layout; in_off counts from the page's first byte)
     uint64_t wsum[T / 64];
+    // wide workgroups only: per position, where PAGE_HOPS headers on would be (low half: distance, saturated; high half:
+    // headers passed, fewer where the chain stops first), and the positions the walk itself stood on
+    uint32_t jc[2][T >= 512 ? PW_WIN : 1];     // (two copies: a round of doubling reads one and writes the other)
+    uint16_t anchor[T >= 512 ? T / 8 + 2 : 1];
     // the walk, between rounds.  Positions count from the 16-byte boundary at or before the page's first byte.
     uint32_t pos;                                 // next header, or next group of the bit-packed run in progress
     uint32_t pending;                             // groups of eight values that run still holds
@@ -1515,11 +1523,51 @@ __device__ inline void page_chase(PageShared<T>& sh, uint32_t cur, uint32_t w_lo
     if (lane == 0) { sh.n_hdr = n; sh.cur_end = p; sh.reason = reason; }
 }
 
+// Phase B for wide workgroups.  Phase A has also worked out, by three rounds of doubling over all positions at once, where
+// the chain stands eight headers on from every position (sh.jc): the walk -- the one part of a page only one wavefront can
+// do, a dependent LDS round trip per step -- takes eight headers per step and notes where it stood; the seven headers
+// behind each of those places are then filled in by a lane per place.
+template <int T>
+__device__ inline void page_chase_hops(PageShared<T>& sh, uint32_t cur, uint32_t w_lo, uint32_t w_hi, uint32_t end) {
+    constexpr uint32_t PW_HDRS = T, HOPS = 1u << PAGE_HOPS_LOG2;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t size = w_hi - w_lo;
+    uint32_t n = 0, na = 0;
+    bool zero = false;
+    cur = pw_uniform(cur);
+    __builtin_amdgcn_s_setprio(3);
+    while (cur < size) {
+        const uint32_t v = pw_uniform(sh.jc[PAGE_HOPS_LOG2 & 1][cur]);
+        const uint32_t c = v >> 16;
+        if (c == 0) { zero = true; break; }       // nothing the round can use starts here
+        if (n + c > PW_HDRS) break;               // the table is full: the next round goes on from here
+        if (lane == 0) sh.anchor[na] = (uint16_t)cur;
+        na++;
+        n += c;
+        cur += v & 0xffffu; // (fewer than HOPS headers: the chain left the window, or stands on a position of distance 0)
+    }
+    __builtin_amdgcn_s_setprio(0);
+    for (uint32_t a = lane; a < na; a += 64) {
+        uint32_t p = sh.anchor[a];
+        for (uint32_t i = 0; i < HOPS && p < size; i++) {
+            const uint32_t d = sh.adv[p];
+            if (d == 0) break;
+            sh.hdr[a * HOPS + i] = (uint16_t)p;
+            p += d;
+        }
+    }
+    const uint32_t p = w_lo + cur;
+    uint32_t reason = 0;
+    if (p >= end) reason = 1;
+    else if (zero && !(p + 4 > w_hi && w_hi < end)) reason = 2;
+    if (lane == 0) { sh.n_hdr = n; sh.cur_end = p; sh.reason = reason; }
+}
+
 // T threads take a page: 256 (four wavefronts share the expansion: long pages), or 64 -- short pages are a chain of
 // dependent steps (descriptor, window, distances, walk, table), and a wavefront that has a SIMD nearly to itself goes
 // through them several times faster than four that share theirs with twenty-eight others and meet at barriers.
 template <int T>
-__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T == 256 ? 8 : 2, 8))) void rle_page_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+__global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T >= 256 ? 8 : 2, 8))) void rle_page_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
                                                      const uint32_t* __restrict__ items, uint32_t* __restrict__ retry_word, uint32_t launch) {
     constexpr uint32_t ET = T; // (shadows the file's workgroup size inside this kernel)
     __shared__ PageShared<T> sh;
@@ -1549,7 +1597,8 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T == 256 ? 8 
         pw_barrier();
         uint32_t state;
 #ifdef PQD_PAGE_TIMING
-        uint64_t t_load = 0, t_walk = 0, t_exp = 0, t0 = __builtin_readcyclecounter(), t1;
+        uint64_t t_load = 0, t_walk = 0, t_exp = 0, t_c = 0, t0 = __builtin_readcyclecounter(), t1;
+        const uint64_t t_first = t0;
 #define PQD_TICK(acc) t1 = __builtin_readcyclecounter(); acc += t1 - t0; t0 = t1;
 #else
 #define PQD_TICK(acc)
@@ -1567,7 +1616,41 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T == 256 ? 8 
             const uint32_t cur0 = pos + gp * bw, pend_vals = gp * 8;
             pw_barrier();
             // ---- A: the distance to the next header, at every position the window holds ----
-            {
+            if constexpr (T >= 512) {
+                constexpr uint32_t PER = PW_WIN / T;
+                const uint32_t* w = sh.win + GROUP_STAGE_PAD / 4;
+                const uint32_t size = w_hi - w_lo;
+                uint32_t jc[PER]; // distance (low half, saturated) and headers passed (high half), as in sh.jc
+#pragma unroll
+                for (uint32_t i = 0; i < PER; i++) {
+                    const uint32_t rel = tid + i * ET;
+                    jc[i] = 0;
+                    if (rel < size) {
+                        const uint32_t dw = rel >> 2;
+                        const uint32_t a0 = __builtin_amdgcn_alignbit(w[dw + 1], w[dw], (rel & 3) * 8);
+                        const uint32_t x = pw_advance(a0, w_lo + rel, w_hi, end, bw);
+                        const uint32_t j = x < 0xffffu ? x : 0xffffu; // anything this long leaves the window
+                        jc[i] = j | (x != 0 ? 0x10000u : 0u);
+                        sh.adv[rel] = (uint16_t)j;
+                        sh.jc[0][rel] = jc[i];
+                    }
+                }
+                pw_barrier();
+                // twice as many headers on per round: a chain that has stopped, or stands behind the window, stays
+                for (uint32_t lvl = 0; lvl < PAGE_HOPS_LOG2; lvl++) {
+#pragma unroll
+                    for (uint32_t i = 0; i < PER; i++) {
+                        const uint32_t rel = tid + i * ET, q = rel + (jc[i] & 0xffffu);
+                        if ((jc[i] >> 16) == (1u << lvl) && q < size) {
+                            const uint32_t v = sh.jc[lvl & 1][q];
+                            const uint32_t j = (jc[i] & 0xffffu) + (v & 0xffffu);
+                            jc[i] = (j < 0xffffu ? j : 0xffffu) | ((jc[i] & 0xffff0000u) + (v & 0xffff0000u));
+                        }
+                        if (rel < size) sh.jc[(lvl + 1) & 1][rel] = jc[i];
+                    }
+                    pw_barrier();
+                }
+            } else {
                 const uint32_t* w = sh.win + GROUP_STAGE_PAD / 4;
                 for (uint32_t rel = tid; rel < w_hi - w_lo; rel += ET) {
                     const uint32_t dw = rel >> 2;
@@ -1575,15 +1658,16 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T == 256 ? 8 
                     const uint32_t x = pw_advance(a0, w_lo + rel, w_hi, end, bw);
                     sh.adv[rel] = (uint16_t)(x < 0xffffu ? x : 0xffffu); // anything this long leaves the window
                 }
+                pw_barrier();
             }
-            pw_barrier();
             PQD_TICK(t_load)
             // ---- B: the chain of headers ----
             if (wave == 0) {
                 if (pend_left > 0) { // the run in progress fills the window
                     if (lane == 0) { sh.n_hdr = 0; sh.cur_end = cur0; sh.reason = 0; }
                 } else {
-                    page_chase(sh, cur0 - w_lo, w_lo, w_hi, end);
+                    if constexpr (T >= 512) page_chase_hops(sh, cur0 - w_lo, w_lo, w_hi, end);
+                    else page_chase(sh, cur0 - w_lo, w_lo, w_hi, end);
                 }
             }
             pw_barrier();
@@ -1644,6 +1728,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T == 256 ? 8 
             }
             pw_barrier();
             state = sh.state;
+            PQD_TICK(t_c)
             if (state == 2) break;
             // ---- D: the values ----
             const uint32_t G1 = (uint32_t)G1_64;
@@ -1669,8 +1754,9 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T == 256 ? 8 
                 res->total = total;
                 res->aux = ~0ull;
 #ifdef PQD_PAGE_TIMING
-                res->arg = (int64_t)t_walk;
+                res->arg = (int64_t)((t_c << 32) | (t_walk & 0xffffffffull));
                 res->consumed = (t_load << 32) | (t_exp & 0xffffffffull);
+                res->total = ((__builtin_readcyclecounter() - t_first) << 32) | (uint32_t)sh.n_runs;
 #endif
 #ifdef PQD_PAGE_TIMING2
                 res->arg = (int64_t)t_entry;
@@ -2705,13 +2791,22 @@ if (plan.slices > 1) {
 #undef PQD_LDS_LAUNCH
 }
 
-void launch_rle_pages(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint32_t n_small, uint32_t* retry_word,
-                      uint32_t launch, hipStream_t stream) {
+void launch_rle_pages(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint32_t n_small, uint32_t threads,
+                      uint32_t* retry_word, uint32_t launch, hipStream_t stream) {
     if (n_items == 0) return;
     if (n_small > n_items) n_small = n_items;
     if (n_small > 0) hipLaunchKernelGGL(rle_page_kernel<64>, dim3(n_small), dim3(64), 0, stream, pages, results, items, retry_word, launch);
-    if (n_small < n_items)
-        hipLaunchKernelGGL(rle_page_kernel<256>, dim3(n_items - n_small), dim3(256), 0, stream, pages, results, items + n_small, retry_word, launch);
+    // The workgroup is sized to the batch: a page is a chain of dependent phases, and what the chip has left over when
+    // there are few pages goes into wider phases (sixteen wavefronts share a window's distances and its expansion, and the
+    // walk takes eight headers a step).  Measured on pages of 128 Ki levels: 1024 threads win up to two pages per compute
+    // unit (512 pages: 53 -> 41 us), 256 threads beyond (640 pages: 58 against 60 us); 512 threads win nowhere.
+    // (`threads`: 0, or the size a test or a measurement asks for)
+    const uint32_t n_big = n_items - n_small;
+    const uint32_t t = threads ? threads : n_big <= 512 ? 1024u : 256u;
+    if (n_big > 0 && t == 1024)
+        hipLaunchKernelGGL(rle_page_kernel<1024>, dim3(n_big), dim3(1024), 0, stream, pages, results, items + n_small, retry_word, launch);
+    else if (n_big > 0)
+        hipLaunchKernelGGL(rle_page_kernel<256>, dim3(n_big), dim3(256), 0, stream, pages, results, items + n_small, retry_word, launch);
     hipLaunchKernelGGL(rle_page_retry_kernel, dim3(n_items < 256 ? n_items : 256), dim3(ET), 0, stream, pages, results, items, n_items, retry_word, launch);
 }
 

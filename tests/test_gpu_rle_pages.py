@@ -1,7 +1,8 @@
 """GPU: repetition / definition level pages (RLE hybrid, rle.go:295-350) through both of their
 paths -- a workgroup per page that follows the run headers and expands the runs in one launch
-(the default), and the index + expand kernels every other RLE page takes (PQD_RLE_PAGE=0) --
-against the CPU checker: same values, statuses, status arguments and value counts.  The shapes
+(the default; with 256 and with 1024 threads to a page, as large and small batches get them: the
+wider one follows the headers eight at a time), and the index + expand kernels every other RLE
+page takes (PQD_RLE_PAGE=0) -- against the CPU checker: same values, statuses, status arguments and value counts.  The shapes
 aim at the page kernel's seams: pages longer than its window, bit-packed runs longer than the
 window, more runs inside a window than its table lists, varints it leaves to the retry kernel,
 damaged pages, a destination that is too small, pages cut to num_values."""
@@ -21,15 +22,21 @@ _ctxs = {}
 
 def _ctx(mode):
     if mode not in _ctxs:
-        old = os.environ.get("PQD_RLE_PAGE")
-        os.environ["PQD_RLE_PAGE"] = "2" if mode == "page" else "0"
+        want = {"PQD_RLE_PAGE": "2" if mode.startswith("page") else "0", "PQD_RLE_PAGE_THREADS": mode[4:] if mode.startswith("page") else None}
+        old = {k: os.environ.get(k) for k in want}
+        for k, v in want.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
         try:
             _ctxs[mode] = pkg().Context(0)
         finally:
-            if old is None:
-                os.environ.pop("PQD_RLE_PAGE", None)
-            else:
-                os.environ["PQD_RLE_PAGE"] = old
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
     return _ctxs[mode]
 
 
@@ -47,7 +54,7 @@ def _uvarint(v):
     return bytes(out)
 
 
-MODES = ("page", "kernels")
+MODES = ("page256", "page1024", "kernels")
 
 
 @pytest.mark.parametrize("mode", MODES)
@@ -142,8 +149,10 @@ def test_cut_and_capacity(mode):
             assert out.arg == (90_000 if k == len(wants) - 1 else full.size), (mode, k, out.arg)
 
 
-def test_many_pages_in_a_batch():
-    # a row group's worth of level pages: the page kernel's grid is the family's item list
+@pytest.mark.parametrize("mode", ["page256", "page1024", "page"])
+def test_many_pages_in_a_batch(mode):
+    # a row group's worth of level pages: the page kernel's grid is the family's item list ("page": the
+    # workgroup sized to the batch, as without any setting)
     P = pkg()
     rng = np.random.default_rng(29)
     specs, wants = [], []
@@ -153,8 +162,26 @@ def test_many_pages_in_a_batch():
         enc = O.rle_encode_levels(v, bw) if k % 2 else O.rle_encode_levels_mr(v, bw)
         specs.append(spec(P.ENC.RLE, P.KIND.LEVELS, enc, bit_width=bw, misalign=k % 16))
         wants.append(O.rle_decode_levels(enc, bw))
-    for k, (out, want) in enumerate(zip(_decode("page", specs), wants)):
+    for k, (out, want) in enumerate(zip(_decode(mode, specs), wants)):
         assert_same(out, want, np.uint8, f"page {k}")
+
+
+def test_more_headers_in_a_window_than_a_round_lists():
+    # runs of two values are two bytes each: a window of 4096 bytes holds 2048 headers, a round lists 256 or 1024
+    # of them, and the wide workgroups' walk has to stop at a multiple of its eight-header steps
+    P = pkg()
+    rng = np.random.default_rng(31)
+    for mode in ("page256", "page1024"):
+        specs, wants = [], []
+        for n_runs in (255, 256, 257, 1023, 1024, 1025, 1031, 5000):
+            vals = rng.integers(0, 4, size=n_runs)
+            vals[1:][vals[1:] == vals[:-1]] ^= 1  # neighbouring runs differ, or the checker's encoder would merge them
+            counts = rng.integers(1, 8, size=n_runs)
+            enc = b"".join(_uvarint(int(c) << 1) + bytes([int(v)]) for c, v in zip(counts, vals))
+            specs.append(spec(P.ENC.RLE, P.KIND.LEVELS, enc, bit_width=2))
+            wants.append(O.rle_decode_levels(enc, 2))
+        for k, (out, want) in enumerate(zip(_decode(mode, specs), wants)):
+            assert_same(out, want, np.uint8, f"{mode} case {k}")
 
 
 @pytest.mark.parametrize("mode", MODES)

@@ -161,6 +161,8 @@ def main():
     for bw in (1, 3):  # the levels of a 1 MiB page of int64 values
         pg = [rle_levels_page(rng, 131072, bw) for _ in range(32)]
         run(f"RLE levels bw{bw} (128 Ki per page)", [p for p, _ in pg], 16, E.RLE, K.LEVELS, bw, 131072, 0, [v for _, v in pg])
+        for rep in (1, 2, 4, 8, 20, 24, 32, 64) if os.environ.get("PQD_RATES_PAGE_COUNTS") else ():
+            run(f"RLE levels bw{bw} (128 Ki per page) batch of {32 * rep}", [p for p, _ in pg], rep, E.RLE, K.LEVELS, bw, 131072, 0, [v for _, v in pg])
     for bw in (1, 3):
         pg = [rle_levels_page(rng, 32768, bw) for _ in range(64)]
         run(f"RLE levels bw{bw} (32 Ki per page)", [p for p, _ in pg], 32, E.RLE, K.LEVELS, bw, 32768, 0, [v for _, v in pg])

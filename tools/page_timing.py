@@ -12,5 +12,5 @@ for n, bw in ((1 << 20, 1), (1 << 17, 3), (1 << 15, 3)):
     specs = [PageSpec(M.pkg.ENC.RLE, M.pkg.KIND.LEVELS, pages[k % 4], bit_width=bw, dst_cap=n) for k in range(reps)]
     for trial in range(3):
         outs = decode_pages(M.ctx, specs, grow=False)
-        w = np.array([o.arg for o in outs]); l = np.array([o.consumed >> 32 for o in outs]); e = np.array([o.consumed & 0xffffffff for o in outs])
-        print(n, bw, "pages", reps, "trial", trial, "bytes", len(pages[0]), "status", outs[0].status, "mean ticks: load+A", int(l.mean()), "chase", int(w.mean()), "C+expand", int(e.mean()))
+        c = np.array([o.arg >> 32 for o in outs]); w = np.array([o.arg & 0xffffffff for o in outs]); l = np.array([o.consumed >> 32 for o in outs]); e = np.array([o.consumed & 0xffffffff for o in outs])
+        print(n, bw, "pages", reps, "trial", trial, "bytes", len(pages[0]), "status", outs[0].status, "mean ticks: load+A", int(l.mean()), "chase", int(w.mean()), "C", int(c.mean()), "expand", int(e.mean()))
