@@ -348,7 +348,7 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
     b->map.resize(n_pages);
 
     // ---- classify ----
-    size_t runs_entries = 0, lengths_entries = 0;
+    size_t runs_entries = 0, lengths_entries = 0, plain_state_entries = 0;
     for (uint64_t i = 0; i < n_pages; i++) {
         const pqd_page& p = pages[i];
         PageMap m = {-1, PQD_OK, 0};
@@ -463,22 +463,22 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
         b->map[i] = m;
     }
 
-    // ---- PLAIN byte arrays: one wavefront per page walks record by record; many workgroups per page find the
-    // records tile by tile first.  Measured on 386 MB of short strings: 256 pages of 1.5 MB 1390 us walked, 340 us
-    // tiled; 2048 pages of 190 KB 406 / 355 us; 16384 pages of 24 KB 430 / 444 us.  Pages of a tile or two gain
-    // nothing from tiles, so the average page decides ----
+    // ---- PLAIN byte arrays: one wavefront per page walks record by record; many workgroups per page take it tile by
+    // tile in one pass.  Measured on short strings (49 bytes a record): 256 pages of 1.5 MB 1390 us walked, 207 us
+    // tiled; 2048 pages of 190 KB 403 / 211 us; 16384 pages of 24 KB 433 / 252 us; 32768 pages of 6 KB 382 / 231 us;
+    // 32768 pages of 1.5 KB 155 / 179 us.  The average page decides ----
     {
         size_t n_plain = 0;
         uint64_t plain_bytes = 0;
         for (const DevPage& d : b->items)
             if (d.family == FAM_PLAIN_BYTE_ARRAY) { n_plain++; plain_bytes += d.src_len; }
-        const bool tiled = ctx->plain_tiled == 1 || (ctx->plain_tiled == 2 && n_plain > 0 && plain_bytes / n_plain >= (64u << 10));
+        const bool tiled = ctx->plain_tiled == 1 || (ctx->plain_tiled == 2 && n_plain > 0 && plain_bytes / n_plain >= (4u << 10));
         b->plain_tiled = tiled;
         if (tiled) {
             for (DevPage& d : b->items) {
                 if (d.family != FAM_PLAIN_BYTE_ARRAY) continue;
                 d.lengths_cap = plain_bytes_scratch_words(d.src_len);
-                lengths_entries += d.lengths_cap;
+                plain_state_entries += d.lengths_cap;
             }
         }
     }
@@ -712,6 +712,7 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
     const size_t o_ck_state_end = carve(0);
     const size_t o_runs = carve(runs_entries * sizeof(Run));
     const size_t o_lengths = carve(lengths_entries * sizeof(int32_t));
+    const size_t o_plain_state = carve(plain_state_entries * sizeof(uint32_t)); // zero whenever a launch starts
     // few DELTA pages: block positions and tile sums for the tile-parallel kernels
     size_t flat_bytes = 0;
     for (int f : {FAM_DELTA32, FAM_DELTA32_CHAINED, FAM_DELTA64}) {
@@ -758,6 +759,7 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
     b->ck.vals = reinterpret_cast<unsigned long long*>(a + o_ck_vals);
     Run* runs = reinterpret_cast<Run*>(a + o_runs);
     int32_t* lengths = reinterpret_cast<int32_t*>(a + o_lengths);
+    int32_t* plain_state = reinterpret_cast<int32_t*>(a + o_plain_state);
     uint8_t* flat = a + o_flat;
     for (DevPage& d : b->items) {
         if (d.flat_cap > 0) {
@@ -772,8 +774,8 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
             d.lengths_cap = 0;
         }
         if (d.family == FAM_PLAIN_BYTE_ARRAY && d.lengths_cap > 0) {
-            d.lengths = lengths;
-            lengths += d.lengths_cap;
+            d.lengths = plain_state;
+            plain_state += d.lengths_cap;
         }
         if (d.family == FAM_DICT_BYTES) {
             DevPage& ix = b->items[d.chain];
@@ -831,6 +833,10 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
     put(o_ck_chunk, ck_chunk.data(), nck * sizeof(uint32_t));
     bool ok = ws != nullptr ? hip_ok(hipMemcpyAsync(a, image, upload_end, hipMemcpyHostToDevice, ws->stream))
                             : hip_ok(hipMemcpy(a, image, upload_end, hipMemcpyHostToDevice));
+    // the tile states of PLAIN byte-array pages start out as zeros (every launch leaves them so again)
+    if (ok && plain_state_entries > 0)
+        ok = ws != nullptr ? hip_ok(hipMemsetAsync(a + o_plain_state, 0, plain_state_entries * sizeof(uint32_t), ws->stream))
+                           : hip_ok(hipMemset(a + o_plain_state, 0, plain_state_entries * sizeof(uint32_t))) && hip_ok(hipStreamSynchronize(nullptr));
     if (!ok) { delete b; return PQD_ERR_DEVICE; }
     b->h_results.resize(n_items);
     *out = b;

@@ -13,12 +13,16 @@
 // sub-chunk; when that is the later lane's guess the two walks link up.  Pointer doubling over
 // the 256 lanes then tells which lanes lie on the chain that starts at the tile's entry and how
 // many records precede each; where the chain arrives at a position a lane had not guessed, that
-// lane walks again from there and the doubling is redone.  Tiles are chained the same way: a
-// first kernel resolves every tile from its own guess, one wavefront per page checks that each
-// tile's guess is where the tile before it ended (walking a tile itself when it is not) and
-// hands every tile its true entry and rank, and a last kernel resolves the tiles again from the
-// true entries, writes the offsets and copies the bytes.  Wrong guesses cost time, never
-// correctness: every position used in the end was reached from the start of the page.
+// lane walks again from there and the doubling is redone.  Tiles are chained the same way, in the
+// same pass: a workgroup resolves its tile from its own guess while the bytes sit in LDS, says in
+// a state word of the tile what it found (entry assumed, exit, records), and looks back over the
+// tiles before it for the nearest one that already knows where the chain really stands behind it;
+// from there the tiles in between are added up as long as each one's guess is where the one
+// before it ended (a tile that guessed wrong resolves again from its true entry and says so).
+// Then the offsets are written and the bytes copied out of the same LDS tile: the page is read
+// once.  Tiles are handed out by a counter per page, in order, so a tile only ever waits for
+// tiles that are already running.  Wrong guesses cost time, never correctness: every position
+// used in the end was reached from the start of the page.
 #include <algorithm>
 
 #include "pqd_internal.h"
@@ -34,11 +38,19 @@ constexpr uint32_t PLOOK = 256;         // bytes staged behind the tile: a lengt
                                         // last lanes want to see the record after their first
 constexpr uint32_t PSTEPS = 6;          // records in a row that make a position a guess
 
-// per tile, words in the page's scratch
-enum : uint32_t { TW_GUESS = 0, TW_EXIT = 1, TW_COUNT = 2, TW_LAST = 3, TW_FLAGS = 4, TW_ENTRY = 5, TW_RANK = 6, TW_PREV = 7, TW_WORDS = 8 };
-// per page, words behind the tiles'
-enum : uint32_t { PW_STATUS = 0, PW_COUNT = 1, PW_END = 2, PW_DST_RANK = 3, PW_DST_OUT = 4, PW_DST_LEN = 5, PW_DST_POS = 6,
-                  PW_OFF_OUT = 7, PW_OFF_POS = 8, PW_WORDS = 16 };
+// A page's state: PW_WORDS 32-bit words, then TS_WORDS 64-bit words per tile.  All of it is zero when a launch starts
+// (cleared when the batch is made, and again by the last kernel of every launch).
+enum : uint32_t { PW_STATUS = 0, PW_COUNT = 1, PW_END = 2, PW_DST_RANK = 3 /* record + 1; 0: none */, PW_DST_OUT = 4, PW_DST_LEN = 5,
+                  PW_DST_POS = 6, PW_OFF_OUT = 7, PW_OFF_POS = 8, PW_TICKET = 9, PW_WORDS = 16 };
+// A tile says what it found in two pairs of words, every word with TS_READY set once written (a pair counts when both are):
+//   A0  what the tile found from its own guess: bit 62 a record of it does not fit the page, bits 32..45 its records, low half
+//       the guess (page position; P_NONE: nothing in the tile looks like a record)
+//   A1  bit 62 it has records, bits 32..45 the last one's tile position; low half where its chain ends
+//   P0  the chain behind the tile, for good: bit 62 it has ended in a record that does not fit, bits 32..61 records so
+//       far, low half where it stands (the record that failed, when one has)
+//   P1  bit 62 there has been a record, low half the last one's page position
+enum : uint32_t { TS_A0 = 0, TS_A1 = 1, TS_P0 = 2, TS_P1 = 3, TS_WORDS = 4 };
+constexpr unsigned long long TS_READY = 1ull << 63, TS_BIT = 1ull << 62;
 
 // how a tile's chain ends, and jump targets of the doubling beyond the lanes
 constexpr uint32_t T_END = 256, T_ERR = 257, T_BROKEN = 258, T_NONE = 259;
@@ -70,6 +82,7 @@ struct PbShared {
     uint32_t wave_sum[PT / 64];
     uint32_t part[4][PT / 64];      // per wavefront: least guess, last lane with one, records, last record
     uint32_t all_ok, first_guess, last_lane, term_lane, term_type, count, last_start;
+    uint32_t ticket, chain[4];      // the tile taken; where the chain stands in front of it (Chain's fields)
 };
 
 __device__ inline void lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -428,196 +441,151 @@ __device__ inline bool resolve_tile_text(PbShared& sh, const Tile& t, uint32_t e
     return true;
 }
 
-// Where the tiles' record-start masks lie in a page's scratch: behind the tiles' and the page's words.
-__device__ inline gptr<uint32_t> masks_of(gptr<uint32_t> words, uint64_t tiles) { return words + tiles * TW_WORDS + PW_WORDS; }
+// Where the chain of records stands between two tiles.
+struct Chain {
+    uint32_t e;       // page position of the next record (of the record that failed, once one has)
+    uint32_t rank;    // records before it
+    uint32_t prev;    // the last of them, or P_NONE
+    uint32_t status;  // 1: a record did not fit the page: the chain has ended
+};
 
-// Pass one: every tile from its own guess.
-__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void plain_bytes_guess_kernel(const DevPage* __restrict__ pages, const uint32_t* __restrict__ items) {
+__device__ inline unsigned long long ts_load(const unsigned long long* w) { return __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void ts_store(unsigned long long* w, unsigned long long v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ inline Chain chain_of(unsigned long long p0, unsigned long long p1) {
+    Chain c;
+    c.e = (uint32_t)p0;
+    c.rank = (uint32_t)(p0 >> 32) & 0x3fffffffu;
+    c.status = (p0 & TS_BIT) ? 1u : 0u;
+    c.prev = (p1 & TS_BIT) ? (uint32_t)p1 : P_NONE;
+    return c;
+}
+
+__device__ inline void publish_chain(unsigned long long* tw, const Chain& c) {
+    ts_store(tw + TS_P0, TS_READY | (c.status ? TS_BIT : 0ull) | (unsigned long long)c.rank << 32 | c.e);
+    ts_store(tw + TS_P1, TS_READY | (c.prev != P_NONE ? TS_BIT | c.prev : 0ull));
+}
+
+// Where the chain stands in front of `tile` (one wavefront; the same in every lane).  Lane l looks at tile - 1 - l: the nearest
+// tile that knows its P words is the base, the tiles between it and this one are added from their A words when the chain
+// enters them where they guessed (or passes over them); a tile that guessed wrong is waited for -- it resolves again
+// from its true entry and then says where the chain stands behind it.
+__device__ inline Chain look_back(unsigned long long* ts, uint32_t tile, uint32_t n) {
+    const uint32_t lane = threadIdx.x & 63;
+    Chain S{0, 0, P_NONE, 0};
+    if (tile == 0) return S;
+    const uint32_t look = std::min(64u, tile);
+    const unsigned long long* mine = ts + (uint64_t)(tile - 1 - (lane < look ? lane : 0)) * TS_WORDS;
+    unsigned long long a0 = 0, a1 = 0, p0 = 0, p1 = 0, has_p;
+    for (;;) {
+        if (lane < look) {
+            for (;;) {
+                p0 = ts_load(mine + TS_P0); p1 = ts_load(mine + TS_P1);
+                if (p0 & p1 & TS_READY) break;
+                a0 = ts_load(mine + TS_A0); a1 = ts_load(mine + TS_A1);
+                if (a0 & a1 & TS_READY) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        has_p = __ballot(lane < look && (p0 & p1 & TS_READY) != 0);
+        if (has_p) break;
+        __builtin_amdgcn_s_sleep(8); // (the tiles further back are on their way: tile 0 knows its P words at once)
+    }
+    const uint32_t b = (uint32_t)__builtin_ctzll(has_p);
+    S = chain_of(lane_u64(p0, b), lane_u64(p1, b));
+    for (uint32_t l = b; l-- > 0;) {
+        const uint32_t t = tile - 1 - l;
+        const uint32_t tend = std::min(t * PTILE + PTILE, n);
+        if (S.status != 0 || S.e >= tend) continue; // the chain has ended, or passes over the tile
+        const unsigned long long x0 = lane_u64(a0, l), x1 = lane_u64(a1, l);
+        if ((uint32_t)x0 == S.e) {
+            S.rank += (uint32_t)(x0 >> 32) & 0x3fffu;
+            if (x1 & TS_BIT) S.prev = t * PTILE + ((uint32_t)(x1 >> 32) & 0x3fffu);
+            S.status = (x0 & TS_BIT) ? 1u : 0u;
+            S.e = (uint32_t)x1;
+        } else {
+            const unsigned long long* tw = ts + (uint64_t)t * TS_WORDS;
+            unsigned long long q0, q1;
+            for (;;) {
+                q0 = ts_load(tw + TS_P0); q1 = ts_load(tw + TS_P1);
+                if (q0 & q1 & TS_READY) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            S = chain_of(lane_u64(q0, 0), lane_u64(q1, 0));
+        }
+    }
+    return S;
+}
+
+// One pass: a workgroup takes the page's next tile, resolves it from its own guess, finds out where the chain really
+// enters it, writes the offsets and copies the bytes.
+__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void plain_bytes_tile_kernel(const DevPage* __restrict__ pages, const uint32_t* __restrict__ items) {
     __shared__ PbShared sh;
     const DevPage& pg = pages[items[blockIdx.x]];
     if (pg.lengths == nullptr) return; // left to the one-wavefront walker
-    const uint64_t tiles = (pg.src_len + PTILE - 1) / PTILE;
-    gptr<uint32_t> words = (gptr<uint32_t>)pg.lengths;
-    for (uint64_t tile = blockIdx.y; tile < tiles; tile += gridDim.y) {
-        const Tile t = make_tile(pg, tile);
-        lds_sync(); // the tile before is done with the shared memory
-        stage_tile(sh, t);
-        lds_sync();
-        if (!resolve_tile_text(sh, t, tile == 0 ? 0u : P_NONE)) resolve_tile(sh, t, tile == 0 ? 0u : P_NONE);
-        {
-            // the record starts of the chain, a bit per byte: the last pass takes them from here when the chain
-            // does enter the tile where this pass assumed
-            const unsigned long long mine = sh.reach[threadIdx.x] ? sh.starts[threadIdx.x] : 0;
-            u32x2_a4 m2 = {(uint32_t)mine, (uint32_t)(mine >> 32)};
-            *(gptr<u32x2_a4>)(masks_of(words, tiles) + (tile * PT + threadIdx.x) * 2) = m2;
-        }
-        if (threadIdx.x == 0) {
-            gptr<uint32_t> w = words + tile * TW_WORDS;
-            const uint32_t type = sh.term_type;
-            if (type == T_NONE) {
-                w[TW_GUESS] = P_NONE; w[TW_EXIT] = 0; w[TW_COUNT] = 0; w[TW_LAST] = P_NONE; w[TW_FLAGS] = 0;
-            } else {
-                w[TW_GUESS] = (uint32_t)t.base + (tile == 0 ? 0u : sh.first_guess);
-                w[TW_EXIT] = (uint32_t)t.base + sh.exit_[sh.term_lane];
-                w[TW_COUNT] = sh.count;
-                w[TW_FLAGS] = type == T_ERR ? 1u : 0u;
-                w[TW_LAST] = sh.count ? (uint32_t)t.base + sh.last_start : P_NONE;
-            }
-        }
-    }
-}
-
-// Pass two, one wavefront per page: each tile's true entry, the records in front of it and the last record
-// before it; the page's record count, where its chain ends and how.  64 tiles at a time: when every tile's
-// guess is where the tiles before it ended, ranks and last records are prefix operations over the lanes;
-// otherwise the window is gone through tile by tile, and a tile that guessed wrong is walked record by record.
-__global__ __launch_bounds__(64) void plain_bytes_chain_kernel(const DevPage* __restrict__ pages, const uint32_t* __restrict__ items) {
-    const DevPage& pg = pages[items[blockIdx.x]];
-    if (pg.lengths == nullptr) return;
-    gptr<const uint8_t> src = as_global(pg.src);
-    const uint32_t n = (uint32_t)pg.src_len;
-    const uint32_t tiles = (n + PTILE - 1) / PTILE;
-    gptr<uint32_t> words = (gptr<uint32_t>)pg.lengths;
-    gptr<uint32_t> page = words + (uint64_t)tiles * TW_WORDS;
-    const uint32_t lane = threadIdx.x;
-    uint32_t e = 0;          // where the chain stands
-    uint32_t rank = 0, prev = P_NONE, status = 0;
-    for (uint32_t t0 = 0; t0 < tiles; t0 += 64) {
-        const uint32_t mine = t0 + lane;
-        const bool have = mine < tiles;
-        uint32_t g = P_NONE, x = 0, c = 0, last = P_NONE, fl = 0;
-        if (have) {
-            gptr<const uint32_t> w = words + (uint64_t)mine * TW_WORDS;
-            g = w[TW_GUESS]; x = w[TW_EXIT]; c = w[TW_COUNT]; last = w[TW_LAST]; fl = w[TW_FLAGS];
-        }
-        const uint32_t base = mine * PTILE, end = have ? std::min(base + PTILE, n) : 0;
-        uint32_t my_entry = P_NONE, my_rank = 0, my_prev = P_NONE;
-        // ---- all at once: where the chain stands in front of every tile if all guesses hold ----
-        bool done = false;
-        if (status == 0) {
-            // the exit of the nearest tile before this one that has records (exits only grow)
-            uint32_t ex = have && g != P_NONE ? x : 0;
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(ex, o); if (lane >= (uint32_t)o) ex = std::max(ex, up); }
-            uint32_t in = __shfl_up(ex, 1);
-            if (lane == 0) in = 0;
-            in = std::max(in, e);
-            // a tile holds when the chain enters it at its guess, or passes over it and it made no guess (a tile that
-            // guessed and is passed over put its exit into `ex`: nothing here can be trusted then)
-            const bool over = in >= end;
-            const bool ok = !have || (over ? g == P_NONE : g == in);
-            const bool bad = have && !over && fl != 0; // a record that does not fit ends the chain: tile by tile from here
-            if (__ballot(!ok || bad) == 0) {
-                const uint32_t cc = have && !over ? c : 0;
-                const uint32_t incl = wave_inclusive_scan(cc);
-                uint32_t lp = have && !over && c > 0 ? last + 1 : 0; // (+1: P_NONE sorts lowest)
-                for (int o = 1; o < 64; o <<= 1) { const uint32_t up = __shfl_up(lp, o); if (lane >= (uint32_t)o) lp = std::max(lp, up); }
-                uint32_t lp_in = __shfl_up(lp, 1);
-                if (lane == 0) lp_in = 0;
-                my_entry = have && !over ? in : P_NONE;
-                my_rank = rank + incl - cc;
-                my_prev = lp_in ? lp_in - 1 : prev;
-                const uint32_t top = std::min(63u, tiles - t0 - 1);
-                rank += lane_u32(incl, top);
-                const uint32_t lp_top = lane_u32(lp, top);
-                if (lp_top) prev = lp_top - 1;
-                e = std::max(e, lane_u32(ex, top));
-                done = true;
-            }
-        }
-        if (!done) {
-            const uint32_t here = std::min(64u, tiles - t0);
-            for (uint32_t i = 0; i < here; i++) {
-                const uint32_t tend = std::min((t0 + i) * PTILE + PTILE, n);
-                uint32_t entry = P_NONE;
-                const uint32_t r0 = rank, p0 = prev;
-                if (status == 0 && e < tend) {
-                    entry = e;
-                    if (lane_u32(g, i) == e) {
-                        rank += lane_u32(c, i);
-                        if (lane_u32(c, i) > 0) prev = lane_u32(last, i);
-                        if (lane_u32(fl, i)) status = 1;
-                        e = lane_u32(x, i);
-                    } else {
-                        // the tile guessed another entry: its records are walked here, one by one
-                        uint32_t q = e;
-                        while (q < tend) {
-                            if (n - q < 4) { status = 1; break; }
-                            const uint32_t len = (uint32_t)src[q] | ((uint32_t)src[q + 1] << 8) | ((uint32_t)src[q + 2] << 16) | ((uint32_t)src[q + 3] << 24);
-                            if (len > n - q - 4) { status = 1; break; }
-                            prev = q;
-                            rank++;
-                            q += 4 + len;
-                        }
-                        e = q;
-                    }
-                }
-                if (lane == i) { my_entry = entry; my_rank = r0; my_prev = p0; }
-            }
-        }
-        if (have) {
-            gptr<uint32_t> w = words + (uint64_t)mine * TW_WORDS;
-            w[TW_ENTRY] = my_entry; w[TW_RANK] = my_rank; w[TW_PREV] = my_prev;
-        }
-    }
-    if (lane == 0) {
-        page[PW_STATUS] = status;
-        page[PW_COUNT] = rank;
-        page[PW_END] = e; // the page's end, or the record that does not fit
-        page[PW_DST_RANK] = P_NONE;
-    }
-}
-
-// Pass three: the tiles again from their true entries; offsets and bytes.
-__global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void plain_bytes_copy_kernel(const DevPage* __restrict__ pages, const uint32_t* __restrict__ items) {
-    __shared__ PbShared sh;
-    const DevPage& pg = pages[items[blockIdx.x]];
-    if (pg.lengths == nullptr) return;
     const uint64_t n = pg.src_len;
-    const uint64_t tiles = (n + PTILE - 1) / PTILE;
-    gptr<uint32_t> words = (gptr<uint32_t>)pg.lengths;
-    gptr<uint32_t> page = words + tiles * TW_WORDS;
+    const uint32_t tiles = (uint32_t)((n + PTILE - 1) / PTILE);
+    uint32_t* page = reinterpret_cast<uint32_t*>(pg.lengths);
+    unsigned long long* ts = reinterpret_cast<unsigned long long*>(page + PW_WORDS);
     gptr<uint8_t> dst = as_global(pg.dst);
     gptr<uint32_t> offsets = as_global(pg.offsets);
     const uint64_t dst_cap = pg.dst_cap, offsets_cap = pg.offsets_cap;
     const uint32_t lane = threadIdx.x;
-    const uint64_t valid_end = page[PW_END];  // bytes from here on belong to no record
     // records [0, off_room) have room for their offset and the one after it; record off_room is the first that has not
     const uint32_t off_room = offsets_cap >= 0x100000000ull ? 0xffffffffu : (uint32_t)(std::max<uint64_t>(offsets_cap, 1) - 1);
-    const uint32_t total = page[PW_COUNT];
-    for (uint64_t tile = blockIdx.y; tile < tiles; tile += gridDim.y) {
-        const Tile t = make_tile(pg, tile);
-        gptr<const uint32_t> w = words + tile * TW_WORDS;
-        const uint32_t entry = w[TW_ENTRY], rank0 = w[TW_RANK], prev0 = w[TW_PREV];
-        const bool as_guessed = entry != P_NONE && entry == w[TW_GUESS] && w[TW_FLAGS] == 0;
-        u32x2_a4 saved = {0, 0};
-        if (as_guessed) saved = *(gptr<const u32x2_a4>)(masks_of(words, tiles) + (tile * PT + lane) * 2);
+    for (;;) {
+        lds_sync(); // the tile before is done with the shared memory
+        if (lane == 0) sh.ticket = __hip_atomic_fetch_add(&page[PW_TICKET], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         lds_sync();
+        const uint32_t tile = sh.ticket;
+        if (tile >= tiles) break;
+        const Tile t = make_tile(pg, tile);
+        unsigned long long* tw = ts + (uint64_t)tile * TS_WORDS;
         stage_tile(sh, t);
         lds_sync();
-        if (as_guessed) {
-            // the first pass walked this very chain: its record starts, and for every sub-chunk where the record
-            // after its last one starts -- the first start in a later sub-chunk, or where the tile's chain ends
-            const unsigned long long mine = (unsigned long long)saved.x | (unsigned long long)saved.y << 32;
-            uint32_t first = mine ? lane * PSUB + (uint32_t)__builtin_ctzll(mine) : P_NONE;
-            uint32_t after = first; // least `first` of this lane and the later ones of the wavefront
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = (uint32_t)__shfl_down((int)after, d);
-                if ((lane & 63) + d < 64 && o < after) after = o;
+        if (!resolve_tile_text(sh, t, tile == 0 ? 0u : P_NONE)) resolve_tile(sh, t, tile == 0 ? 0u : P_NONE);
+        // ---- what the tile found, for the tiles behind it; where the chain stands in front of it ----
+        const uint32_t type = sh.term_type;
+        const uint32_t my_guess = type == T_NONE ? P_NONE : (uint32_t)t.base + (tile == 0 ? 0u : sh.first_guess);
+        const uint32_t my_exit = type == T_NONE ? 0u : (uint32_t)t.base + sh.exit_[sh.term_lane];
+        const uint32_t my_count = type == T_NONE ? 0u : sh.count, my_last = sh.last_start;
+        const bool my_err = type == T_ERR;
+        if (lane < 64) {
+            if (lane == 0) {
+                ts_store(tw + TS_A0, TS_READY | (my_err ? TS_BIT : 0ull) | (unsigned long long)my_count << 32 | my_guess);
+                ts_store(tw + TS_A1, TS_READY | (my_count ? TS_BIT | (unsigned long long)my_last << 32 : 0ull) | my_exit);
             }
-            if ((lane & 63) == 0) sh.part[0][lane >> 6] = after;
-            uint32_t later = (uint32_t)__shfl_down((int)after, 1);
-            if ((lane & 63) == 63) later = P_NONE;
-            lds_sync();
-            for (uint32_t wv = PT / 64 - 1; wv > (lane >> 6); wv--) later = std::min(later, sh.part[0][wv]);
-            sh.starts[lane] = mine;
-            sh.exit_[lane] = later != P_NONE ? later : w[TW_EXIT] - (uint32_t)t.base;
-            lds_sync();
-        } else if (entry != P_NONE) {
-            if (!resolve_tile_text(sh, t, entry - (uint32_t)t.base)) resolve_tile(sh, t, entry - (uint32_t)t.base);
+            const Chain S = look_back(ts, tile, (uint32_t)n);
+            if (lane == 0) { sh.chain[0] = S.e; sh.chain[1] = S.rank; sh.chain[2] = S.prev; sh.chain[3] = S.status; }
         }
-        else { sh.starts[lane] = 0; sh.reach[lane] = 0; lds_sync(); }
+        lds_sync();
+        const Chain S{sh.chain[0], sh.chain[1], sh.chain[2], sh.chain[3]};
+        const uint32_t tend = (uint32_t)t.base + t.bytes;
+        const uint32_t entry = S.status == 0 && S.e < tend ? S.e : P_NONE;
+        const uint32_t rank0 = S.rank, prev0 = S.prev;
+        Chain P = S;
+        uint32_t vend = S.status ? S.e : 0xffffffffu; // bytes from here on belong to no record
+        lds_sync(); // (sh.chain is written again for the next tile)
+        if (entry == P_NONE) {
+            sh.starts[lane] = 0; sh.reach[lane] = 0;
+        } else {
+            if (entry != my_guess) {
+                if (!resolve_tile_text(sh, t, entry - (uint32_t)t.base)) resolve_tile(sh, t, entry - (uint32_t)t.base);
+            }
+            const uint32_t ty = sh.term_type; // (the chain enters the tile, so it has an end)
+            P.e = (uint32_t)t.base + sh.exit_[sh.term_lane];
+            P.rank = S.rank + sh.count;
+            if (sh.count) P.prev = (uint32_t)t.base + sh.last_start;
+            P.status = ty == T_ERR ? 1u : 0u;
+            if (ty == T_ERR) vend = P.e;
+        }
+        if (lane == 0) {
+            publish_chain(tw, P);
+            if (tile == tiles - 1) { page[PW_STATUS] = P.status; page[PW_COUNT] = P.rank; page[PW_END] = P.e; }
+        }
         // ---- records in front of every sub-chunk: a prefix sum over the lanes ----
-        unsigned long long starts = sh.starts[lane];
+        const unsigned long long starts = sh.reach[lane] ? sh.starts[lane] : 0;
+        sh.starts[lane] = starts;
         {
             const uint32_t c = (uint32_t)__builtin_popcountll(starts);
             const uint32_t incl = wave_inclusive_scan(c);
@@ -631,7 +599,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
         {
             uint32_t k = rank0 + sh.before[lane];  // the record's number in the page
             unsigned long long m = starts;
-            while (m && k < total) {                // (the record that failed is not one)
+            while (m) {
                 const uint32_t bit = (uint32_t)__builtin_ctzll(m);
                 m &= m - 1;
                 // (positions, and so output positions and lengths, fit 32 bits on this path)
@@ -641,17 +609,9 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
                 if (k < off_room) offsets[k] = out;
                 else if (k == off_room) { page[PW_OFF_OUT] = out; page[PW_OFF_POS] = pos; }
                 if (out <= dst_cap && (uint64_t)out + len > dst_cap) {
-                    page[PW_DST_RANK] = k; page[PW_DST_OUT] = out; page[PW_DST_LEN] = len; page[PW_DST_POS] = pos;
+                    page[PW_DST_RANK] = k + 1; page[PW_DST_OUT] = out; page[PW_DST_LEN] = len; page[PW_DST_POS] = pos;
                 }
                 k++;
-            }
-            // records past the page's count (what follows a record that failed) are nobody's
-            if (rank0 + sh.before[lane] + (uint32_t)__builtin_popcountll(starts) > total) {
-                unsigned long long keep = starts;
-                uint32_t drop = rank0 + sh.before[lane] + (uint32_t)__builtin_popcountll(starts) - total;
-                while (drop-- && keep) keep &= ~(1ull << (63 - (uint32_t)__builtin_clzll(keep)));
-                starts = keep;
-                sh.starts[lane] = starts;
             }
         }
         // ---- the bytes of length fields: four from every start, some of them in the next sub-chunk ----
@@ -669,7 +629,7 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
         lds_sync();
         // ---- the copy: a thread takes 16 bytes of the tile at a time, neighbours take neighbouring bytes ----
         // (page positions and output positions fit 32 bits on this path; so does the capacity that matters)
-        const uint32_t cap32 = dst_cap > 0xffffffffull ? 0xffffffffu : (uint32_t)dst_cap, vend = (uint32_t)valid_end;
+        const uint32_t cap32 = dst_cap > 0xffffffffull ? 0xffffffffu : (uint32_t)dst_cap;
         for (uint32_t c16 = lane; c16 * 16 < t.bytes; c16 += PT) {
             const uint32_t at = c16 * 16, sub = at / PSUB, sh_bits = at % PSUB;
             const unsigned long long st = sh.starts[sub], hd = sh.headers[sub];
@@ -751,47 +711,52 @@ __global__ __launch_bounds__(PT) __attribute__((amdgpu_waves_per_eu(6, 6))) void
     }
 }
 
-// Pass four, one thread per page: the page's result (plain.go:76-94 walks record by record: the first
-// record that fails in any way decides).
-__global__ void plain_bytes_finish_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
-                                          const uint32_t* __restrict__ items, uint32_t n_items) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_items) return;
-    const DevPage& pg = pages[items[i]];
+// Behind it, a workgroup per page: the page's result (plain.go:76-94 walks record by record: the first record that
+// fails in any way decides), and the page's state cleared for the next launch.
+__global__ __launch_bounds__(PT) void plain_bytes_finish_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
+                                                                const uint32_t* __restrict__ items) {
+    const DevPage& pg = pages[items[blockIdx.x]];
     if (pg.lengths == nullptr) return;
-    DevResult* res = &results[items[i]];
+    DevResult* res = &results[items[blockIdx.x]];
     const uint64_t n = pg.src_len;
     const uint64_t tiles = (n + PTILE - 1) / PTILE;
-    gptr<const uint32_t> page = (gptr<const uint32_t>)pg.lengths + tiles * TW_WORDS;
-    const uint64_t total = page[PW_COUNT], end = page[PW_END];
-    const uint64_t offsets_cap = pg.offsets_cap;
-    // candidates, by record number: the record the offsets have no room for, the record the destination has
-    // no room for, the record that does not fit the page
-    const uint64_t k_off = std::max<uint64_t>(offsets_cap, 1) - 1;
-    const uint64_t k_dst = page[PW_DST_RANK] == P_NONE ? ~0ull : page[PW_DST_RANK];
-    int32_t status = PQD_OK;
-    int64_t arg = 0;
-    uint64_t values = total, bytes = end - 4 * total, consumed = n;
-    if (k_off < total && k_off <= k_dst) {
-        status = PQD_ERR_OFFSETS_TOO_SMALL; arg = (int64_t)(k_off + 2);
-        values = k_off; bytes = page[PW_OFF_OUT]; consumed = page[PW_OFF_POS];
-    } else if (k_dst < total) {
-        status = PQD_ERR_DST_TOO_SMALL; arg = (int64_t)((uint64_t)page[PW_DST_OUT] + page[PW_DST_LEN]);
-        values = k_dst; bytes = page[PW_DST_OUT]; consumed = page[PW_DST_POS];
-    } else if (page[PW_STATUS] != 0) {
-        status = PQD_ERR_UNEXPECTED_EOF; arg = PQD_EOF_PLAIN_BYTE_ARRAY;
-        consumed = end;
-    } else if (total + 1 > offsets_cap) {
-        status = PQD_ERR_OFFSETS_TOO_SMALL; arg = (int64_t)(total + 1);
-    } else {
-        as_global(pg.offsets)[total] = (uint32_t)bytes;
+    gptr<uint32_t> page = (gptr<uint32_t>)pg.lengths;
+    if (threadIdx.x == 0) {
+        const uint64_t total = page[PW_COUNT], end = page[PW_END];
+        const uint64_t offsets_cap = pg.offsets_cap;
+        // candidates, by record number: the record the offsets have no room for, the record the destination has
+        // no room for, the record that does not fit the page
+        const uint64_t k_off = std::max<uint64_t>(offsets_cap, 1) - 1;
+        const uint64_t k_dst = page[PW_DST_RANK] == 0 ? ~0ull : (uint64_t)page[PW_DST_RANK] - 1;
+        int32_t status = PQD_OK;
+        int64_t arg = 0;
+        uint64_t values = total, bytes = end - 4 * total, consumed = n;
+        if (k_off < total && k_off <= k_dst) {
+            status = PQD_ERR_OFFSETS_TOO_SMALL; arg = (int64_t)(k_off + 2);
+            values = k_off; bytes = page[PW_OFF_OUT]; consumed = page[PW_OFF_POS];
+        } else if (k_dst < total) {
+            status = PQD_ERR_DST_TOO_SMALL; arg = (int64_t)((uint64_t)page[PW_DST_OUT] + page[PW_DST_LEN]);
+            values = k_dst; bytes = page[PW_DST_OUT]; consumed = page[PW_DST_POS];
+        } else if (page[PW_STATUS] != 0) {
+            status = PQD_ERR_UNEXPECTED_EOF; arg = PQD_EOF_PLAIN_BYTE_ARRAY;
+            consumed = end;
+        } else if (total + 1 > offsets_cap) {
+            status = PQD_ERR_OFFSETS_TOO_SMALL; arg = (int64_t)(total + 1);
+        } else {
+            as_global(pg.offsets)[total] = (uint32_t)bytes;
+        }
+        res->status = status;
+        res->arg = arg;
+        res->out_values = values;
+        res->out_bytes = bytes;
+        res->consumed = consumed;
+        res->total = values;
     }
-    res->status = status;
-    res->arg = arg;
-    res->out_values = values;
-    res->out_bytes = bytes;
-    res->consumed = consumed;
-    res->total = values;
+    // (the wavefront's loads above are done before any of its lanes goes on: one instruction stream)
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    const uint64_t quads = (PW_WORDS + tiles * TS_WORDS * 2) / 4; // (a page's state starts on a 16-byte boundary and is a whole number of them)
+    for (uint64_t w = threadIdx.x; w < quads; w += PT) *(gptr<u32x4>)(page + 4 * w) = u32x4{0, 0, 0, 0};
 }
 
 } // namespace
@@ -799,7 +764,7 @@ __global__ void plain_bytes_finish_kernel(const DevPage* __restrict__ pages, Dev
 uint64_t plain_bytes_scratch_words(uint64_t src_len) {
     // pages this path does not take: positions are kept in 32 bits
     if (src_len == 0 || src_len > 0xfff00000ull) return 0;
-    return ((src_len + PTILE - 1) / PTILE) * (TW_WORDS + 2 * PT) + PW_WORDS;
+    return ((src_len + PTILE - 1) / PTILE) * (TS_WORDS * 2) + PW_WORDS;
 }
 
 void launch_plain_byte_array(const DevPage* pages, DevResult* results, const uint32_t* items, uint32_t n_items, uint64_t max_bytes,
@@ -807,11 +772,11 @@ void launch_plain_byte_array(const DevPage* pages, DevResult* results, const uin
     if (n_items == 0) return;
     launch_plain_byte_array_walk(pages, results, items, n_items, stream); // the pages without scratch
     if (max_bytes == 0) return;                                           // (no page has any)
+    // (tiles are handed out by the pages' counters: a workgroup goes on until its page has none left, so the grid need not
+    // hold a workgroup for every tile of the longest page)
     const uint32_t gy = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(1, (max_bytes + PTILE - 1) / PTILE), 16384);
-    hipLaunchKernelGGL(plain_bytes_guess_kernel, dim3(n_items, gy), dim3(PT), 0, stream, pages, items);
-    hipLaunchKernelGGL(plain_bytes_chain_kernel, dim3(n_items), dim3(64), 0, stream, pages, items);
-    hipLaunchKernelGGL(plain_bytes_copy_kernel, dim3(n_items, gy), dim3(PT), 0, stream, pages, items);
-    hipLaunchKernelGGL(plain_bytes_finish_kernel, dim3((n_items + 63) / 64), dim3(64), 0, stream, pages, results, items, n_items);
+    hipLaunchKernelGGL(plain_bytes_tile_kernel, dim3(n_items, gy), dim3(PT), 0, stream, pages, items);
+    hipLaunchKernelGGL(plain_bytes_finish_kernel, dim3(n_items), dim3(PT), 0, stream, pages, results, items);
 }
 
 } // namespace pqd

@@ -147,3 +147,45 @@ def test_tiled_decode_is_repeatable():
         for (label, values), out in zip(cases, _decode(True, specs)):
             assert out.status == 0 and out.out_values == len(values), (trip, label)
             assert out.data.tobytes() == b"".join(values), (trip, label)
+
+
+def test_one_batch_launched_again_and_again():
+    # the tiles of a page find their places through state words in the batch's scratch that every launch has to
+    # leave as it found them: the same batch object, launched four times into cleared destinations, one of its
+    # pages damaged half way (its chain ends there, and the tiles behind it have nothing to copy)
+    import torch
+    P = pkg()
+    rng = np.random.default_rng(23)
+    values = [bytes(rng.integers(97, 123, size=int(k), dtype=np.uint8)) for k in rng.integers(0, 120, size=9000)]
+    good = _page(values)
+    bad = bytearray(good)
+    at = sum(4 + len(v) for v in values[:5000])
+    bad[at: at + 4] = (len(good)).to_bytes(4, "little")
+    encs = [good, bytes(bad), good[: len(good) // 3 * 2 + 1]]
+    wants = [O.plain_decode_byte_array(e) for e in encs]
+    dev = torch.device("cuda:0")
+    src = [torch.from_numpy(np.frombuffer(e, np.uint8).copy()).to(dev) for e in encs]
+    dst = [torch.zeros(len(good) + 64, dtype=torch.uint8, device=dev) for _ in encs]
+    off = [torch.zeros(len(values) + 8, dtype=torch.int32, device=dev) for _ in encs]
+    pages = []
+    for k, e in enumerate(encs):
+        p = P.Page()
+        p.src, p.src_len = src[k].data_ptr(), len(e)
+        p.dst, p.dst_cap = dst[k].data_ptr(), len(good)
+        p.offsets, p.offsets_cap = off[k].data_ptr(), len(values) + 1
+        p.num_values = -1
+        p.encoding, p.kind, p.bit_width = P.ENC.PLAIN, P.KIND.BYTE_ARRAY, 0
+        pages.append(p)
+    batch = P.Batch(_ctx(True), pages)
+    stream = torch.cuda.current_stream().cuda_stream
+    for trip in range(4):
+        for d, o in zip(dst, off):
+            d.zero_(); o.zero_()
+        torch.cuda.synchronize()
+        batch.launch(stream)
+        res = batch.finish(stream)
+        for k, want in enumerate(wants):
+            assert (res[k].status, res[k].status_arg, res[k].out_values) == (want.status, want.arg, want.n_values), (trip, k)
+            nb = int(want.values.size)
+            assert dst[k][:nb].cpu().numpy().tobytes() == want.values.tobytes(), (trip, k)
+            assert np.array_equal(off[k][: want.n_values].cpu().numpy().view(np.uint32), want.offsets[: want.n_values]), (trip, k)

@@ -216,6 +216,10 @@ def main():
     tj = [np.frombuffer(b"".join(v), np.uint8) for v in tiny]
     tnb = max(j.size for j in tj)
     run("PLAIN byte arrays urls (512)", [plain_ba_page(v) for v in tiny], 256, E.PLAIN, K.BYTE_ARRAY, 0, tnb, 512, tj, steps=5)
+    for per in (128, 32) if os.environ.get("PQD_RATES_PAGE_COUNTS") else ():  # pages of 6 KB and 1.5 KB
+        t2 = [strings(rng, per) for _ in range(64)]
+        t2j = [np.frombuffer(b"".join(v), np.uint8) for v in t2]
+        run(f"PLAIN byte arrays urls ({per})", [plain_ba_page(v) for v in t2], 512, E.PLAIN, K.BYTE_ARRAY, 0, max(j.size for j in t2j), per, t2j, steps=5)
 
 
 if __name__ == "__main__":
