@@ -876,7 +876,7 @@ __global__ __launch_bounds__(WT) void dba_kernel(const DevPage* __restrict__ pag
 //   dba_block_kernel   per block: suffix bytes, output bytes, least prefix length, validity;
 //   dba_plan_kernel    per page: exclusive sums over the blocks, the page-level checks, and the
 //                      decision whether the page takes this path (anything unusual -- an error,
-//                      FIXED_LEN_BYTE_ARRAY, very long values -- is left to dba_kernel, which
+//                      very long values -- is left to dba_kernel, which
 //                      reports errors exactly as the sequential decoder does);
 //   dba_expand_kernel  a wavefront per run of consecutive blocks, a lane per value: the bytes the
 //                      first block of the run inherits from earlier values are looked up by
@@ -904,10 +904,14 @@ __device__ inline uint32_t wave_min_u32(uint32_t v) {
     return v;
 }
 
+// (FIXED_LEN_BYTE_ARRAY pages are the same decode without offsets: byte_array_purego.go:36-63 checks what
+// decodeByteArray checks, and nothing about the type length but its range, byte_array.go:149-151)
 __device__ inline bool dba_parallel_candidate(const DevPage& pg, const DevResult& rp, const DevResult& rs) {
-    return pg.kind == PQD_KIND_BYTE_ARRAY && pg.tile_run != nullptr && rp.status == PQD_OK && rs.status == PQD_OK &&
+    const bool with_offsets = pg.kind == PQD_KIND_BYTE_ARRAY;
+    const bool fixed = pg.kind == PQD_KIND_FIXED_LEN_BYTE_ARRAY && pg.bit_width >= 0 && (uint32_t)pg.bit_width <= MAX_FLBA;
+    return (with_offsets || fixed) && pg.tile_run != nullptr && rp.status == PQD_OK && rs.status == PQD_OK &&
            rp.out_values == rs.out_values && rs.out_values > 0 && rs.out_values <= pg.lengths_cap &&
-           rs.out_values + 1 <= pg.offsets_cap && rs.out_values < 0x7fffffffull;
+           (!with_offsets || rs.out_values + 1 <= pg.offsets_cap) && rs.out_values < 0x7fffffffull;
 }
 
 // grid.x = pages, grid.y = slots; a wavefront takes a block of 64 values at a time.
@@ -1044,6 +1048,7 @@ __global__ __launch_bounds__(WT) void dba_expand_kernel(const DevPage* __restric
     const uint64_t data_total = pg.src_len - rs.consumed;
     gptr<uint8_t> dst = as_global(pg.dst);
     gptr<uint32_t> offsets = as_global(pg.offsets);
+    const bool with_offsets = pg.kind == PQD_KIND_BYTE_ARRAY;
     uint32_t* img32 = reinterpret_cast<uint32_t*>(img);
     const uint32_t* carry32 = reinterpret_cast<const uint32_t*>(carry);
 
@@ -1079,8 +1084,10 @@ __global__ __launch_bounds__(WT) void dba_expand_kernel(const DevPage* __restric
         const uint32_t block_bytes = lane_u32(xo, 63);
         const uint32_t s_at = base_s + xs - s;  // where this value's suffix bytes start in the data section
         const uint32_t o_rel = xo - len;        // where the value starts in the block's output
-        if (valid) offsets[k] = base_o + o_rel;
-        if (k + 1 == ns) offsets[ns] = base_o + xo;
+        if (with_offsets) {
+            if (valid) offsets[k] = base_o + o_rel;
+            if (k + 1 == ns) offsets[ns] = base_o + xo;
+        }
         const uint32_t align = (uint32_t)((uintptr_t)(dst + base_o) & 15);
         const uint32_t q = align + o_rel;       // the value's place in the image
         // the first twelve suffix bytes of every value, in flight while the inherited bytes are looked up

@@ -181,6 +181,10 @@ def main():
     nb = max(j.size for j in joined)
     run("DELTA_LENGTH_BYTE_ARRAY urls (32 Ki)", [dlba_page(v) for v in svals], 64, E.DELTA_LENGTH_BYTE_ARRAY, K.BYTE_ARRAY, 0, nb, 32768, joined)
     run("DELTA_BYTE_ARRAY urls (32 Ki)", [dba_page(v) for v in svals], 64, E.DELTA_BYTE_ARRAY, K.BYTE_ARRAY, 0, nb, 32768, joined, steps=5)
+    # FIXED_LEN_BYTE_ARRAY through DELTA_BYTE_ARRAY: sorted 16-byte keys (big-endian counters with random gaps)
+    keys = [[int(x).to_bytes(16, "big") for x in np.cumsum(rng.integers(1, 1 << 40, size=65536, dtype=np.int64).astype(object)) + (1 << 100)] for _ in range(4)]
+    kj = [np.frombuffer(b"".join(v), np.uint8) for v in keys]
+    run("DELTA_BYTE_ARRAY fixed 16 (64 Ki)", [dba_page(v) for v in keys], 64, E.DELTA_BYTE_ARRAY, K.FIXED_LEN_BYTE_ARRAY, 16, 16 * 65536, 0, kj, steps=5)
     run("PLAIN byte arrays urls (32 Ki)", [plain_ba_page(v) for v in svals], 64, E.PLAIN, K.BYTE_ARRAY, 0, nb, 32768, joined, steps=5)
     # the same kind of strings through a dictionary of 4096 of them: indexes of 12 bits, one bit-packed run per page
     words = sorted(set(strings(rng, 6000)))[:4096]
