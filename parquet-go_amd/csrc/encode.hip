@@ -880,65 +880,193 @@ __global__ __launch_bounds__(ET) void levels_encode_write_kernel(EncPage* __rest
 // ----------------------------------------------------------------- RLE booleans --
 
 // encodeBits (rle.go:97-139) over the packed bits, behind the 4-byte length EncodeBoolean puts in front
-// (rle.go:48-56).  Where a run ends depends on where it began and on what kind it is, byte by byte; a
-// boolean page is an eighth of a byte per value, so this first form walks it with one lane per page:
-// long stretches of equal bytes are skipped eight at a time.  Two passes of the same walk: sizes, then bytes.
-__device__ inline uint64_t bits_encode_walk(gptr<const uint8_t> src, uint64_t n, gptr<uint8_t> dst, bool write) {
-    uint64_t o = 0;
-    auto put_uvarint = [&](uint64_t v) {
-        while (v >= 0x80) { if (write) dst[o] = (uint8_t)(v | 0x80); o++; v >>= 7; }
-        if (write) dst[o] = (uint8_t)v;
-        o++;
-    };
-    auto same_until = [&](uint64_t i) { // first j > i with src[j] != src[i]
-        const uint8_t b = src[i];
-        const uint64_t bb = (uint64_t)b * 0x0101010101010101ull;
-        uint64_t j = i + 1;
-        while (j + 8 <= n && *(gptr<const u64_a1e>)(src + j) == bb) j += 8;
-        while (j < n && src[j] == b) j++;
-        return j;
-    };
-    bool uniform = n == 0;
-    if (n > 0 && (src[0] == 0 || src[0] == 0xff)) uniform = same_until(0) == n;
-    if (uniform) { // rle.go:98-104
-        put_uvarint((8 * n) << 1);
-        if (n > 0) { if (write) dst[o] = src[0]; o++; }
-        return o;
+// (rle.go:48-56).  The reference walks the bytes: at a byte of zeros or ones that repeats it writes a run of
+// repeats; anywhere else a bit-packed run that goes on until two equal bytes follow one another (0xff never
+// stops it, rle.go:125) and then gives the first of the two back.  Where its runs start is nevertheless a local
+// matter.  In terms of the stretches of equal bytes: a stretch of two or more zero bytes is always a run of
+// repeats (whatever run comes before it stops at its first byte); a stretch of two or more 0xff bytes is one
+// only if a run starts at its first byte, which is the case at the start of the page and right behind a run of
+// repeated zeros, and nowhere else (a bit-packed run swallows it); every byte of a stretch of two or more other
+// bytes starts a run (bit-packed runs of one byte, the last one going on); and a run starts behind every run of
+// repeats.  So: flags per byte from its neighbours, "this stretch is a run of repeats" handed along each stretch,
+// the starts counted and listed, the runs sized and placed by a prefix sum, the packed bytes copied.  A
+// workgroup takes a page, 4 KB at a time, three times over (list, place, copy): boolean pages are small, and a
+// page a workgroup is enough to keep many of them busy.
+constexpr uint32_t BE_T = 256, BE_PER = 16, BE_CHUNK = BE_T * BE_PER;
+
+struct BeShared {
+    uint32_t wave_starts[BE_T / 64];
+    uint32_t wave_has[BE_T / 64], wave_g[BE_T / 64];
+    unsigned long long wave_bytes[BE_T / 64];
+};
+
+// The starts among the sixteen bytes [i0, i0 + 16) of the page (bit j: byte i0 + j) and which of them start runs of
+// repeats; g_carry: whether the stretch that holds the last byte before this chunk is a run of repeats (in and out).
+__device__ inline void be_flags(BeShared& sh, gptr<const uint8_t> src, uint32_t n, uint32_t c0, uint32_t& starts, uint32_t& repeats,
+                                uint32_t& g_carry) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t i0 = c0 + tid * BE_PER;
+    uint32_t w[5] = {0, 0, 0, 0, 0}; // bytes i0 - 2 .. i0 + 17 from bit 16 of w[0] on
+    uint8_t by[BE_PER + 3];
+#pragma unroll
+    for (uint32_t j = 0; j < BE_PER + 3; j++) {
+        const int64_t at = (int64_t)i0 + j - 2;
+        by[j] = at >= 0 && at < (int64_t)n ? src[at] : 0;
     }
-    for (uint64_t i = 0; i < n;) {
-        uint64_t j = i + 1;
-        if (src[i] == 0 || src[i] == 0xff) {
-            j = same_until(i);
-            if (j - i > 1) {
-                put_uvarint((8 * (j - i)) << 1);
-                if (write) dst[o] = src[i];
-                o++;
-                i = j;
-                continue;
-            }
-        }
-        while (j < n && (src[j - 1] != src[j] || src[j] == 0xff)) j++; // rle.go:125: `src[j] != 0 && src[j] == 0xFF`
-        if (j - i > 1 && j < n) j--;
-        put_uvarint(((j - i) << 1) | 1);
-        if (write) for (uint64_t k = i; k < j; k++) dst[o + (k - i)] = src[k];
-        o += j - i;
-        i = j;
+    (void)w;
+    uint32_t run_start = 0, g0 = 0, vrun = 0, valid = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < BE_PER; j++) {
+        const uint32_t i = i0 + j;
+        if (i >= n) break;
+        const uint8_t c = by[j + 2];
+        const bool eqp = i > 0 && by[j + 1] == c, eqn = i + 1 < n && by[j + 3] == c;
+        const bool zz_before = i >= 2 && by[j + 1] == 0 && by[j] == 0;
+        const bool rs = !eqp;
+        const bool rep = rs && eqn && (c == 0 || (c == 0xff && (i == 0 || zz_before)));
+        valid |= 1u << j;
+        if (rs) run_start |= 1u << j;
+        if (rep || (n == 1 && (c == 0 || c == 0xff))) g0 |= 1u << j; // (a page of one byte of zeros or ones: rle.go:98-104)
+        if (c != 0 && c != 0xff && (eqp || eqn)) vrun |= 1u << j;
     }
-    return o;
+    // ---- is the stretch a byte lies in a run of repeats: its first byte says, the others hear it from the byte before ----
+    const bool has = run_start != 0;
+    const bool last_g = has ? ((g0 >> (31 - __builtin_clz(run_start))) & 1) != 0 : false; // as far as this thread knows
+    const unsigned long long hs = __ballot(has), lg = __ballot(last_g);
+    if (lane == 0) { sh.wave_has[wave] = hs != 0; sh.wave_g[wave] = hs ? (uint32_t)((lg >> (63 - __builtin_clzll(hs))) & 1) : 0u; }
+    __syncthreads();
+    uint32_t g_in = g_carry; // of the byte before this thread's first
+    for (uint32_t wv = 0; wv < wave; wv++) if (sh.wave_has[wv]) g_in = sh.wave_g[wv];
+    {
+        const unsigned long long below = hs & ((1ull << lane) - 1);
+        if (below) g_in = (uint32_t)((lg >> (63 - __builtin_clzll(below))) & 1);
+    }
+    uint32_t g_out = g_carry;
+    for (uint32_t wv = 0; wv < BE_T / 64; wv++) if (sh.wave_has[wv]) g_out = sh.wave_g[wv];
+    g_carry = g_out;
+    uint32_t after = 0, g = g_in;
+#pragma unroll
+    for (uint32_t j = 0; j < BE_PER; j++) {
+        if (!((valid >> j) & 1)) break;
+        if ((run_start >> j) & 1) { if (g) after |= 1u << j; g = (g0 >> j) & 1; }
+    }
+    starts = (g0 | after | vrun | (i0 == 0 ? 1u : 0u)) & valid;
+    repeats = g0 & valid;
+    __syncthreads(); // (sh.wave_* are written again by the next call)
 }
 
-__global__ __launch_bounds__(64) void bits_encode_kernel(EncPage* __restrict__ pages, const uint32_t* __restrict__ items, uint32_t n_items) {
-    const uint32_t k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= n_items) return;
-    EncPage& pg = pages[items[k]];
+__device__ inline uint32_t be_uvarint_len(uint64_t v) { uint32_t k = 1; while (v >= 0x80) { v >>= 7; k++; } return k; }
+
+__global__ __launch_bounds__(BE_T) void bits_encode_kernel(EncPage* __restrict__ pages, const uint32_t* __restrict__ items) {
+    __shared__ BeShared sh;
+    EncPage& pg = pages[items[blockIdx.x]];
     gptr<const uint8_t> src = as_global(pg.src);
     gptr<uint8_t> dst = as_global(pg.dst);
-    const uint64_t body = bits_encode_walk(src, pg.n_values, dst, false);
+    gptr<uint32_t> pos = (gptr<uint32_t>)as_global(pg.len_a);   // where run k starts (bit 31: a run of repeats), n + 1 entries
+    gptr<uint32_t> shift = (gptr<uint32_t>)as_global(pg.len_b); // bit-packed run k: its bytes go to body position i + shift[k]
+    const uint32_t n = (uint32_t)pg.n_values, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t cap = pg.dst_cap;
+    if (n == 0) { // rle.go:98-104: the header of an empty run
+        if (tid == 0) {
+            const bool ok = cap >= 5;
+            if (ok) { dst[0] = 1; dst[1] = 0; dst[2] = 0; dst[3] = 0; dst[4] = 0; }
+            pg.status = ok ? PQD_OK : PQD_ERR_DST_TOO_SMALL; pg.arg = ok ? 0 : 5; pg.out_bytes = ok ? 5 : 0;
+        }
+        return;
+    }
+    // ---- the runs' starts, listed ----
+    uint32_t m = 0, g_carry = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += BE_CHUNK) {
+        uint32_t starts, repeats;
+        be_flags(sh, src, n, c0, starts, repeats, g_carry);
+        const uint32_t mine = (uint32_t)__builtin_popcount(starts);
+        const uint32_t incl = wave_inclusive_scan<uint32_t>(mine);
+        if (lane == 63) sh.wave_starts[wave] = incl;
+        __syncthreads();
+        uint32_t k = m + incl - mine, all = 0;
+        for (uint32_t wv = 0; wv < BE_T / 64; wv++) { if (wv < wave) k += sh.wave_starts[wv]; all += sh.wave_starts[wv]; }
+        for (uint32_t b = starts; b; b &= b - 1) {
+            const uint32_t j = (uint32_t)__builtin_ctz(b);
+            pos[k++] = (c0 + tid * BE_PER + j) | (((repeats >> j) & 1) << 31);
+        }
+        m += all;
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- their sizes and places; the headers ----
+    uint64_t body = 0;
+    for (uint32_t k0 = 0; k0 < m; k0 += BE_T) {
+        const uint32_t k = k0 + tid;
+        uint32_t p = 0, len = 0, hdr = 0;
+        bool rep = false;
+        uint64_t head = 0;
+        if (k < m) {
+            const uint32_t e = pos[k];
+            p = e & 0x7fffffffu; rep = (e >> 31) != 0;
+            len = (k + 1 < m ? pos[k + 1] & 0x7fffffffu : n) - p;
+            head = rep ? ((uint64_t)8 * len) << 1 : ((uint64_t)len << 1) | 1; // rle.go:416-427
+            hdr = be_uvarint_len(head);
+        }
+        const unsigned long long size = k < m ? (rep ? hdr + 1ull : (unsigned long long)hdr + len) : 0ull;
+        const unsigned long long incl = wave_inclusive_scan<uint64_t>(size);
+        if (lane == 63) sh.wave_bytes[wave] = incl;
+        __syncthreads();
+        unsigned long long at = body + incl - size, all = 0;
+        for (uint32_t wv = 0; wv < BE_T / 64; wv++) { if (wv < wave) at += sh.wave_bytes[wv]; all += sh.wave_bytes[wv]; }
+        if (k < m) {
+            if (4 + at + hdr + (rep ? 1 : 0) <= cap) {
+                uint64_t v = head;
+                uint32_t o = 0;
+                while (v >= 0x80) { dst[4 + at + o++] = (uint8_t)(v | 0x80); v >>= 7; }
+                dst[4 + at + o] = (uint8_t)v;
+                if (rep) dst[4 + at + hdr] = src[p];
+            }
+            shift[k] = (uint32_t)(at + hdr) - p;
+        }
+        body += all;
+        __syncthreads();
+    }
     const uint64_t bytes = 4 + body;
-    if (bytes > pg.dst_cap) { pg.status = PQD_ERR_DST_TOO_SMALL; pg.arg = (int64_t)bytes; pg.out_bytes = 0; return; }
-    for (uint32_t b = 0; b < 4; b++) dst[b] = (uint8_t)((uint32_t)body >> (8 * b));
-    bits_encode_walk(src, pg.n_values, dst + 4, true);
-    pg.status = PQD_OK; pg.arg = 0; pg.out_bytes = bytes;
+    if (bytes > cap) {
+        if (tid == 0) { pg.status = PQD_ERR_DST_TOO_SMALL; pg.arg = (int64_t)bytes; pg.out_bytes = 0; }
+        return;
+    }
+    if (tid < 4) dst[tid] = (uint8_t)((uint32_t)body >> (8 * tid));
+    __threadfence_block();
+    __syncthreads();
+    // ---- the packed bytes of the bit-packed runs ----
+    uint32_t rank = 0;
+    g_carry = 0;
+    for (uint32_t c0 = 0; c0 < n; c0 += BE_CHUNK) {
+        uint32_t starts, repeats;
+        be_flags(sh, src, n, c0, starts, repeats, g_carry);
+        const uint32_t mine = (uint32_t)__builtin_popcount(starts);
+        const uint32_t incl = wave_inclusive_scan<uint32_t>(mine);
+        if (lane == 63) sh.wave_starts[wave] = incl;
+        __syncthreads();
+        uint32_t k = rank + incl - mine, all = 0; // runs that start before this thread's first byte
+        for (uint32_t wv = 0; wv < BE_T / 64; wv++) { if (wv < wave) k += sh.wave_starts[wv]; all += sh.wave_starts[wv]; }
+        const uint32_t i0 = c0 + tid * BE_PER;
+        if (i0 < n) {
+            const uint32_t have = n - i0 < BE_PER ? n - i0 : BE_PER;
+            if (starts == 0 && have == BE_PER) {
+                // sixteen bytes of one run (k >= 1: byte 0 starts a run)
+                if (!(pos[k - 1] >> 31)) *(gptr<u32x4_a1e>)(dst + 4 + (uint32_t)(i0 + shift[k - 1])) = *(gptr<const u32x4_a1e>)(src + i0);
+            } else {
+                uint32_t sft = 0;
+                bool packed = false;
+                if (k > 0) { packed = !(pos[k - 1] >> 31); sft = shift[k - 1]; }
+                for (uint32_t j = 0; j < have; j++) {
+                    if ((starts >> j) & 1) { packed = !(pos[k] >> 31); sft = shift[k]; k++; }
+                    if (packed) dst[4 + (uint32_t)(i0 + j + sft)] = src[i0 + j];
+                }
+            }
+        }
+        rank += all;
+        __syncthreads();
+    }
+    if (tid == 0) { pg.status = PQD_OK; pg.arg = 0; pg.out_bytes = bytes; }
 }
 
 // ------------------------------------------------------------------ byte arrays --
@@ -1390,6 +1518,8 @@ static void plan_encode(const pqd_encode_page* in, uint64_t n, EncodePlan& plan,
             }
         }
     }
+    // boolean pages: where each run starts, and where its bytes go (a run may be a single byte)
+    for (uint32_t i : plan.fam_items[EF_BOOL]) len_values += 2 * ((plan.pages[i].n_values + 64) & ~(size_t)63);
     // the state words of all tiled families lie in one block, cleared before every launch
     uint64_t tiles = 0;
     for (int f : TILED_FAMILIES) {
@@ -1433,6 +1563,12 @@ static void place_scratch(EncodePlan& plan, uint8_t* ws) {
         tile += plan.fam_prefix[f].back();
     }
     int32_t* len = reinterpret_cast<int32_t*>(ws + plan.o_len);
+    for (uint32_t i : plan.fam_items[EF_BOOL]) {
+        EncPage& e = plan.pages[i];
+        const size_t room = (e.n_values + 64) & ~(size_t)63;
+        e.len_a = len; len += room;
+        e.len_b = len; len += room;
+    }
     for (int f : {EF_DLBA, EF_DBA}) {
         for (uint32_t i : plan.fam_items[f]) {
             EncPage& e = plan.pages[i];
@@ -1582,7 +1718,7 @@ int pqd_encode_batch(pqd_ctx* ctx, pqd_encode_page* pages, uint64_t n_pages, voi
     if (const uint32_t np = (uint32_t)plan.fam_items[EF_PLAIN_BA].size())
         hipLaunchKernelGGL(plain_ba_encode_kernel, dim3(np, ba_grid_y(plan.ba_max_values, ET)), dim3(ET), 0, s, d_pages, items_of(EF_PLAIN_BA));
     if (const uint32_t np = (uint32_t)plan.fam_items[EF_BOOL].size())
-        hipLaunchKernelGGL(bits_encode_kernel, dim3((np + 63) / 64), dim3(64), 0, s, d_pages, items_of(EF_BOOL), np);
+        hipLaunchKernelGGL(bits_encode_kernel, dim3(np), dim3(BE_T), 0, s, d_pages, items_of(EF_BOOL));
     if (plan.fam_prefix[EF_LEVELS].back()) {
         const int f = EF_LEVELS;
         const uint32_t np = (uint32_t)plan.fam_items[f].size();

@@ -313,6 +313,12 @@ def test_rle_boolean_bytes():
             v[k: k + int(rng.integers(1, 12))] = v[k]
         cases.append(v)
         cases.append(np.repeat(rng.choice(np.array([0, 0xFF, 7], np.uint8), size=n // 3 + 1), 3)[:n])
+    # stretches that cross the 4096-byte steps of the kernel: 0xFF behind zeros, 0xFF behind something else, long runs
+    for lead in (4090, 4094, 4095, 4096, 8191):
+        cases.append(np.concatenate([np.zeros(lead, np.uint8), np.full(9000, 0xFF, np.uint8), np.full(5, 3, np.uint8), np.zeros(4100, np.uint8)]))
+        cases.append(np.concatenate([rng.integers(1, 255, size=lead - 1, dtype=np.uint8), np.array([0], np.uint8), np.full(4100, 0xFF, np.uint8), np.zeros(2, np.uint8),
+                                     np.full(3, 0xFF, np.uint8), np.full(4097, 0x11, np.uint8)]))
+    cases.append(rng.choice(np.array([0, 0xFF, 0x55], np.uint8), size=70000))
     outs = _encode([(P.ENC.RLE, P.KIND.BOOLEAN, v, 0) for v in cases], misalign=1)
     for k, (v, (status, arg, page, raw)) in enumerate(zip(cases, outs)):
         want = bytes(O.rle_encode_boolean(v))

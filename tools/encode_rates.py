@@ -1,5 +1,6 @@
 """Device-resident rates of the page encoders: DELTA_BINARY_PACKED int64 / int32 on the headline's
-page shape, RLE_DICTIONARY index pages, BYTE_STREAM_SPLIT, and the dictionary bounds.  Values are
+page shape, RLE_DICTIONARY index pages, RLE levels and booleans, BYTE_STREAM_SPLIT, the three byte-array
+encodings, and the dictionary and page bounds.  Values are
 generated on the host, placed in HBM once, encoded as one batch per line; the time is the whole
 pqd_encode_batch call (descriptor upload, kernels, results back, one synchronisation), the kernels'
 own durations come from rocprofv3 --kernel-trace over this script.  Output is checked against the
@@ -24,17 +25,24 @@ DEV = "cuda:0"
 rng = np.random.default_rng(4)
 
 
-def run(name, uniq, replicate, encoding, kind, bit_width, check, steps=10):
-    """uniq: list of numpy value arrays; each is used `replicate` times (distinct copies in HBM)."""
+def run(name, uniq, replicate, encoding, kind, bit_width, check, steps=10, offsets=None):
+    """uniq: list of numpy value arrays; each is used `replicate` times (distinct copies in HBM).  offsets: per entry of
+    uniq, the n + 1 offsets of byte-array values (uniq then holds their bytes)."""
     n_pages = len(uniq) * replicate
-    srcs, caps, ns = [], [], []
+    srcs, caps, ns, offs = [], [], [], []
     for k in range(n_pages):
         v = uniq[k % len(uniq)]
         t = torch.from_numpy(v.view(np.uint8).copy()).to(DEV)
         n = v.size // bit_width if kind == pkg.KIND.FIXED_LEN_BYTE_ARRAY else v.size
+        if offsets is not None:
+            o = offsets[k % len(uniq)]
+            n = o.size - 1
+            offs.append(torch.from_numpy(o.astype(np.uint32).view(np.int32).copy()).to(DEV))
+            caps.append(int(L.pqd_encode_bound_byte_array(encoding, n, v.size)))
+        else:
+            caps.append(int(L.pqd_encode_bound(encoding, kind, bit_width, n)))
         srcs.append(t)
         ns.append(n)
-        caps.append(int(L.pqd_encode_bound(encoding, kind, bit_width, n)))
     slot = (max(caps) + 255) // 256 * 256
     dst = torch.empty(n_pages * slot, dtype=torch.uint8, device=DEV)
     pages = (EncodePage * n_pages)()
@@ -42,6 +50,8 @@ def run(name, uniq, replicate, encoding, kind, bit_width, check, steps=10):
         p = pages[k]
         p.src, p.n_values, p.dst, p.dst_cap = srcs[k].data_ptr(), ns[k], dst.data_ptr() + k * slot, slot
         p.encoding, p.kind, p.bit_width = encoding, kind, bit_width
+        if offsets is not None:
+            p.offsets, p.src_bytes = offs[k].data_ptr(), uniq[k % len(uniq)].size
     ws = torch.empty(int(L.pqd_encode_workspace_size(pages, n_pages)) + 256, dtype=torch.uint8, device=DEV)
     stream = torch.cuda.current_stream(0).cuda_stream
 
@@ -57,10 +67,11 @@ def run(name, uniq, replicate, encoding, kind, bit_width, check, steps=10):
         best = min(best, time.perf_counter() - t0)
     assert all(pages[k].status == 0 for k in range(n_pages))
     out_bytes = sum(pages[k].out_bytes for k in range(n_pages))
-    in_bytes = sum(u.nbytes for u in uniq) * replicate
+    in_bytes = (sum(u.nbytes for u in uniq) + (sum(4 * o.size for o in offsets) if offsets is not None else 0)) * replicate
     host = dst.cpu().numpy()
     for k in list(range(min(3, n_pages))) + [n_pages - 1]:
-        assert host[k * slot: k * slot + pages[k].out_bytes].tobytes() == check(uniq[k % len(uniq)]), (name, k)
+        want = check(uniq[k % len(uniq)]) if offsets is None else check(uniq[k % len(uniq)], offsets[k % len(uniq)])
+        assert host[k * slot: k * slot + pages[k].out_bytes].tobytes() == want, (name, k)
     print(f"{name:44s} {n_pages:5d} pages  {best * 1e6:9.1f} us per call  values {in_bytes / 1e6:8.1f} MB -> pages {out_bytes / 1e6:8.1f} MB  "
           f"{in_bytes / best / 1e9:7.1f} GB/s of values, {(in_bytes + out_bytes) / best / 1e9:7.1f} GB/s read + written", flush=True)
 
@@ -93,6 +104,43 @@ run("BYTE_STREAM_SPLIT double 256 Ki", dbl, 32, E.BYTE_STREAM_SPLIT, K.DOUBLE, 0
 flt = [rng.standard_normal(524288).astype(np.float32) for _ in range(8)]
 run("BYTE_STREAM_SPLIT float 512 Ki", flt, 32, E.BYTE_STREAM_SPLIT, K.FLOAT, 0, lambda v: bytes(O.bss_encode(v.tobytes(), 4)))
 
+
+# levels as a nullable column makes them: runs of nulls among defined values (the shape tools/misc_rates.py decodes)
+def levels_of(n, bw):
+    out = np.empty(n, np.uint8)
+    at = 0
+    while at < n:
+        if rng.random() < 0.5:
+            k = min(n - at, 8 * int(rng.integers(1, 64)))
+            out[at: at + k] = rng.integers(0, 1 << bw, size=k)
+        else:
+            k = min(n - at, int(rng.geometric(1 / 4096)))
+            out[at: at + k] = rng.integers(0, 1 << bw)
+        at += k
+    return out
+
+
+for bw in (1, 3):
+    lv = [levels_of(131072, bw) for _ in range(16)]
+    run(f"RLE levels bw{bw} 128 Ki", lv, 32, E.RLE, K.LEVELS, bw, lambda v, bw=bw: bytes(O.rle_encode_levels(v, bw)))
+# booleans: the packed bits of 1 Mi values per page, stretches of equal values among mixed ones
+bl = [np.packbits(levels_of(1 << 20, 1), bitorder="little") for _ in range(8)]
+run("RLE boolean 1 Mi values (128 KB of bits)", bl, 64, E.RLE, K.BOOLEAN, 0, lambda v: bytes(O.rle_encode_boolean(v)))
+
+
+def strings(n):
+    heads = [b"https://www.example.com/catalog/items/", b"https://cdn.example.org/static/img/", b"http://a.io/",
+             b"https://api.example.net/v2/accounts/transactions/history/", b"ftp://files.example.com/pub/"]
+    vals = sorted(heads[int(h)] + b"%08d" % int(t) for h, t in zip(rng.integers(0, 5, size=n), rng.integers(0, 10**8, size=n)))
+    return np.frombuffer(b"".join(vals), np.uint8), np.concatenate([[0], np.cumsum([len(v) for v in vals])]).astype(np.uint32), vals
+
+
+sv = [strings(32768) for _ in range(4)]
+sd, so = [d for d, _, _ in sv], [o for _, o, _ in sv]
+run("PLAIN byte arrays urls 32 Ki", sd, 64, E.PLAIN, K.BYTE_ARRAY, 0, lambda d, o: bytes(O.plain_encode_byte_array([d[o[i]: o[i + 1]].tobytes() for i in range(o.size - 1)])), steps=5, offsets=so)
+run("DELTA_LENGTH_BYTE_ARRAY urls 32 Ki", sd, 64, E.DELTA_LENGTH_BYTE_ARRAY, K.BYTE_ARRAY, 0, lambda d, o: bytes(O.dlba_encode(data=d, offsets=o)), steps=5, offsets=so)
+run("DELTA_BYTE_ARRAY urls 32 Ki", sd, 64, E.DELTA_BYTE_ARRAY, K.BYTE_ARRAY, 0, lambda d, o: bytes(O.dba_encode(data=d, offsets=o)), steps=5, offsets=so)
+
 # dictionary bounds: 16 Mi indexes into a 64 Ki-entry int64 dictionary
 d = torch.from_numpy(rng.integers(-2**62, 2**62, size=65536, dtype=np.int64)).to(DEV)
 ix = torch.from_numpy(rng.integers(0, 65536, size=1 << 24, dtype=np.int32)).to(DEV)
@@ -114,3 +162,16 @@ us = ev[0].elapsed_time(ev[1]) * 100
 g = d[ix.long()]
 assert out.tolist() == [int(g.min()), int(g.max())] and st.tolist() == [0, 0]
 print(f"{'dictionaryBounds int64, 16 Mi indexes, 64 Ki entries':44s}        {us:9.1f} us per call  {ix.numel() * 4 / us / 1e3:7.1f} GB/s of indexes", flush=True)
+
+# page bounds: the min / max of 16 Mi int64 values of a page that is not dictionary-encoded
+vals = torch.from_numpy(rng.integers(-2**62, 2**62, size=1 << 24, dtype=np.int64)).to(DEV)
+for _ in range(3):
+    assert L.pqd_page_bounds_device(ctx.handle, K.INT64, 0, vals.data_ptr(), vals.numel(), out.data_ptr(), bws.data_ptr(), bws.numel(), st.data_ptr(), stream) == 0
+ev[0].record()
+for _ in range(10):
+    L.pqd_page_bounds_device(ctx.handle, K.INT64, 0, vals.data_ptr(), vals.numel(), out.data_ptr(), bws.data_ptr(), bws.numel(), st.data_ptr(), stream)
+ev[1].record()
+torch.cuda.synchronize()
+us = ev[0].elapsed_time(ev[1]) * 100
+assert out.tolist() == [int(vals.min()), int(vals.max())] and st.tolist() == [0, 0]
+print(f"{'page bounds int64, 16 Mi values':44s}        {us:9.1f} us per call  {vals.numel() * 8 / us / 1e3:7.1f} GB/s of values", flush=True)
