@@ -1,12 +1,14 @@
 """GPU: pqd_optional_expand_noalloc (the entry point whose workspace is a static device array,
 for callers that cannot allocate) against pqd_optional_expand_device on the same inputs,
-through the C ABI, bit exact; two calls in a row, the second smaller, so that what the first
-left in the shared array would show."""
+through the C ABI, bit exact, and both against the numpy restatement of page_optional.go:72-117
+(oracle/levels_oracle.py); two calls in a row, the second smaller, so that what the first left in
+the shared array would show."""
 import ctypes as C
 
 import numpy as np
 import pytest
 
+from oracle import levels_oracle as LO
 from tests.gpu_util import ctx, pkg
 
 pytestmark = pytest.mark.gpu
@@ -61,6 +63,15 @@ def test_noalloc_matches_the_workspace_entry_point_twice_in_a_row():
         assert got[2] == want[2] == [present, 0], (n, width)
         assert np.array_equal(got[0], want[0]), (n, width, offsets_mode)
         assert np.array_equal(got[1], want[1]), (n, width, offsets_mode)
+        # and what the reference's ReadValues leaves in the slots
+        if offsets_mode:
+            ref = LO.optional_offsets(d, max_def, vals)
+            assert np.array_equal(got[0][: 4 * n].view(np.uint32), ref[:n]), (n, "offsets")
+        else:
+            slots, validity, cnt, eof = LO.optional_read_values(d, max_def, vals, width)
+            assert cnt == present and not eof
+            assert np.array_equal(got[0][: n * width], slots), (n, width)
+            assert np.array_equal(got[1][:n], validity), (n, width)
 
 
 def test_noalloc_runs_out_of_values_like_the_workspace_entry_point():
