@@ -57,6 +57,9 @@ def _pages(rng):
     out.append(("long", rand(30, 5000, 70000) + [b"x"] + rand(4, 100000, 200000) + [b"tail"]))     # records longer than tiles
     out.append(("long-then-short", rand(3, 40000, 50000) + rand(5000, 0, 30) + rand(2, 17000, 33000) + rand(5000, 40, 60)))
     out.append(("tile-edges", [b"a" * 16380, b"b" * 16376, b"", b"c" * 3, b"d" * 16383, b"e" * 16384, b"f"]))
+    out.append(("none", []))                                                                       # an empty page among the others
+    out.append(("exactly-a-tile", [b"q" * 12] * 1024))                                              # 16 bytes a record: 16384 bytes
+    out.append(("a-tile-and-a-byte", [b"q" * 12] * 1023 + [b"q" * 13]))
     out.append(("single", [b"only"]))
     out.append(("single-long", [bytes(rng.integers(0, 256, size=100001, dtype=np.uint8))]))
     return out
