@@ -191,3 +191,41 @@ def test_lookup_entry_point_on_device_pointers():
     assert rc == 0 and st.tolist()[:2] == [P.STATUS.INDEX_OUT_OF_BOUNDS, 77]
     assert L.pqd_dict_lookup_bytes_device(ctx().handle, P.KIND.INT64, d_t.data_ptr(), None, 300, 8, i_t.data_ptr(), 1, dst.data_ptr(), 8,
                                           None, 0, st.data_ptr(), stream) == P.STATUS.NOT_SUPPORTED
+
+
+@pytest.mark.parametrize("dict_misalign", [0, 1, 7, 15])
+def test_small_dictionaries_at_every_alignment(dict_misalign):
+    """Look-ups of many values in small dictionaries through the stand-alone entry point: dictionaries and destinations
+    at every alignment, one or two values of tens of kilobytes, values long enough that 64 of them pass the
+    wavefront's image, empty values."""
+    import torch
+    P = pkg()
+    L = P.lib()
+    rng = np.random.default_rng(46 + dict_misalign)
+    stream = C.c_void_p(torch.cuda.current_stream(0).cuda_stream)
+    shapes = [(4096, 11), (4097, 11), (1500, 60), (1600, 61), (3, 0), (40, 900), (1, 48 << 10), (2, 24 << 10), (300, 150)]
+    for dn, max_len in shapes:
+        if dn <= 2:
+            lens = np.full(dn, max_len)
+            offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.uint32)
+            data = rng.integers(0, 256, size=int(offs[-1]), dtype=np.uint8)
+        else:
+            data, offs = _ba_dict(rng, dn, max_len)
+        n = 4096 if dn <= 2 else 30001
+        idx = rng.integers(0, dn, size=n, dtype=np.int32)
+        want, want_offs = _ba_lookup(data, offs, idx)
+        raw = torch.zeros(data.size + 64, dtype=torch.uint8, device="cuda")
+        raw[dict_misalign: dict_misalign + data.size] = torch.from_numpy(data).cuda()
+        o_t, i_t = torch.from_numpy(offs.view(np.int32)).cuda(), torch.from_numpy(idx).cuda()
+        a = (dict_misalign * 5) % 16
+        dst = torch.full((want.size + 64 + a,), 0xA5, dtype=torch.uint8, device="cuda")
+        out_offs = torch.zeros(n + 1, dtype=torch.int32, device="cuda")
+        st = torch.zeros(3, dtype=torch.int64, device="cuda")
+        rc = L.pqd_dict_lookup_bytes_device(ctx().handle, P.KIND.BYTE_ARRAY, raw.data_ptr() + dict_misalign, o_t.data_ptr(), dn, 0, i_t.data_ptr(), n,
+                                            dst.data_ptr() + a, want.size, out_offs.data_ptr(), n + 1, st.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert rc == 0 and st.tolist() == [0, 0, want.size], (dn, max_len)
+        got = dst.cpu().numpy()
+        assert got[a: a + want.size].tobytes() == want.tobytes(), (dn, max_len)
+        assert (got[:a] == 0xA5).all() and (got[a + want.size:] == 0xA5).all(), (dn, max_len)
+        assert np.array_equal(out_offs.cpu().numpy().view(np.uint32), want_offs), (dn, max_len)
