@@ -343,6 +343,9 @@ constexpr uint32_t TBL_BLOCKS = TBL_TILES * 8; // blocks one walk can describe
 constexpr uint32_t HDR_MAX = 10 + 32; // longest block header the fast path reads
 constexpr uint64_t FAST_MAX_BYTES = 0xfff00000ull; // pages the fast path addresses with 32-bit offsets
 constexpr uint32_t NO_POS = 0xffffffffu;
+#ifndef PQD_DELTA_ROTATE
+#define PQD_DELTA_ROTATE 4 // tiles between two changes of a workgroup's priority; 0: the priority is left alone
+#endif
 
 // Everything below is in ring space (byte offsets from the 16-byte aligned
 // base of the page), 32 bits wide.
@@ -438,6 +441,9 @@ __global__ __launch_bounds__(DT) __attribute__((amdgpu_waves_per_eu(8, 8), amdgp
 void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict__ results,
                        const uint32_t* __restrict__ items) {
     __shared__ FastShared sh;
+#ifdef PQD_DELTA_TIMING
+    const uint64_t t_entry = __builtin_readcyclecounter();
+#endif
     const uint32_t item = items[blockIdx.x];
     const DevPage& pg = pages[item];
     DevResult* res = &results[item];
@@ -653,16 +659,28 @@ void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict_
                     ring_16(sh.ring, at, qlo, qhi);
                     uint32_t k, wd;
                     quick_header(qlo, qhi, k, wd);
-                    const int64_t md = unzigzag(quick_uvarint(qlo, qhi, k));
+                    // The four width bytes are fetched again from the ring (two dwords and a funnel shift) and they and
+                    // the offsets go to LDS before the min delta is worked out: taken out of the sixteen bytes with
+                    // 64-bit shifts that depend on k and kept across the varint, they did not fit the kernel's 64
+                    // registers, the compiler parked them in scratch memory, and the reload waited for every global
+                    // store this wavefront still had in flight, with the other three wavefronts at the barrier behind it.
+                    {
+                        const uint32_t wp = at + k, wdw = (wp & RING_MASK) >> 2;
+                        wd = __builtin_amdgcn_alignbit(sh.ring[wdw + 1], sh.ring[wdw], (wp & 3) * 8); // the mirror covers wdw + 1
+                    }
                     uint32_t off = at + k + 4;
 #pragma unroll
                     for (uint32_t m = 0; m < 4; m++) {
-                        Slot sl;
-                        sl.min_delta = md; sl.off = off; sl.bw = (wd >> (8 * m)) & 0xff;
-                        sh.slots[lane * 4 + m] = sl;
-                        off += (w_vpm >> 3) * sl.bw;
+                        const uint32_t bw = (wd >> (8 * m)) & 0xff;
+                        sh.slots[lane * 4 + m].off = off;
+                        sh.slots[lane * 4 + m].bw = bw;
+                        off += (w_vpm >> 3) * bw;
                     }
                     sh.blk_end[lane] = off;
+                    asm volatile("" ::: "memory");
+                    const int64_t md = unzigzag(quick_uvarint(qlo, qhi, k));
+#pragma unroll
+                    for (uint32_t m = 0; m < 4; m++) sh.slots[lane * 4 + m].min_delta = md;
                 }
                 // keep whole tiles unless the stream or the page ends inside the table
                 const bool page_end = found == blocks_left && !ended;
@@ -729,12 +747,29 @@ void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict_
             break;
         }
 
+#if PQD_DELTA_ROTATE > 0
+        // The hardware lets the oldest wavefront of a SIMD issue first: of the workgroups that share a compute unit
+        // the first to arrive then finishes first (in 0.72 M cycles of the last one's 1.28 M, eight to a unit) and
+        // the last ones decode their tails with the unit half empty.  A priority that goes round the workgroups
+        // keeps them together; those of one unit are 256 apart in a grid that fills the chip once, which is what
+        // the term from blockIdx spreads over the four levels (any other grid gets some other, as good, spread).
+        if ((done & (PQD_DELTA_ROTATE * TILE - 1)) == 0) {
+            const uint32_t level = (((done / (PQD_DELTA_ROTATE * TILE)) + (blockIdx.x >> 8)) & 7) >> 1;
+            if (level == 0) __builtin_amdgcn_s_setprio(0);
+            else if (level == 1) __builtin_amdgcn_s_setprio(1);
+            else if (level == 2) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(3);
+        }
+#endif
         // ---- prefetch: chunks the NEXT tile wants resident, requested now and written to
-        // the ring at the top of the next iteration.  Both loads are issued on every
-        // iteration (of a dummy address when there is nothing to fetch) and every thread
-        // then issues exactly two stores, so the wait for these loads at the top of the
-        // next iteration is a fixed "all but the two youngest operations".  Addresses are
-        // clamped, so a load is always legal; ring_put discards what lies past the end. ----
+        // the ring at the top of the next iteration.  When there is something to fetch both
+        // loads are issued (the second of a dummy address if one chunk is enough) and every
+        // thread then issues exactly two stores, so the wait for these loads at the top of
+        // the next iteration is a fixed "all but the two youngest operations"; a tile that
+        // fetches nothing issues no load, and the next one then waits for nothing: its
+        // stores go out behind this tile's without anybody having waited for these.
+        // Addresses are clamped, so a load is always legal; ring_put discards what lies
+        // past the end. ----
         const uint32_t lo_next = sh.fc.tile_lo[tbl_next + 1];
         const uint32_t c_want = lo_next / CHUNK + LOOK / CHUNK; // last chunk the next tile wants
         pf_n = c_next > c_want ? 0u : (c_want + 1 - c_next > 2 ? 2u : c_want + 1 - c_next);
@@ -743,9 +778,9 @@ void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict_
         // stream of stores is dear whatever its size, so 8 KB every few tiles beats 4 KB twice as often.
         if (c_next > lo_next / CHUNK + LOOK_MIN / CHUNK && lo_next - lo <= 3072) pf_n = 0;
         pf_v = c_next * CHUNK + tq * 16u;
-        {
+        if (pf_n > 0) {
             const uint32_t pv1 = pf_v + CHUNK;
-            pf0 = *(gptr<const u32x4>)(base + (pf_n > 0 && pf_v < end ? pf_v : 0u));
+            pf0 = *(gptr<const u32x4>)(base + (pf_v < end ? pf_v : 0u));
             pf1 = *(gptr<const u32x4>)(base + (pf_n > 1 && pv1 < end ? pv1 : 0u));
         }
 
@@ -775,6 +810,15 @@ void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict_
         res->consumed = src_skip + (consumed - mis);
         res->n_runs = 0;
         res->aux = FAST_DONE;
+#ifdef PQD_DELTA_TIMING
+        // where and when this workgroup ran, in place of the fields a caller reads (tools/delta_timing.py)
+        uint32_t xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        res->arg = (int64_t)t_entry;
+        res->consumed = __builtin_readcyclecounter();
+        res->out_values = ((uint64_t)(xcc & 0xf) << 32) | hw;
+#endif
     }
 }
 
