@@ -752,9 +752,12 @@ void delta_fast_kernel(const DevPage* __restrict__ pages, DevResult* __restrict_
         // the first to arrive then finishes first (in 0.72 M cycles of the last one's 1.28 M, eight to a unit) and
         // the last ones decode their tails with the unit half empty.  A priority that goes round the workgroups
         // keeps them together; those of one unit are 256 apart in a grid that fills the chip once, which is what
-        // the term from blockIdx spreads over the four levels (any other grid gets some other, as good, spread).
+        // the term from blockIdx tells apart (any other grid gets some other spread over the four levels, as good).
         if ((done & (PQD_DELTA_ROTATE * TILE - 1)) == 0) {
-            const uint32_t level = (((done / (PQD_DELTA_ROTATE * TILE)) + (blockIdx.x >> 8)) & 7) >> 1;
+            // (the turn a workgroup has, doubled, plus its place among the eight: between two workgroups of one level the
+            // older one still goes first, so the later a workgroup arrived the more of its time it spends a level up)
+            const uint32_t slot8 = (blockIdx.x >> 8) & 7, rot8 = ((done / (PQD_DELTA_ROTATE * TILE)) + slot8) & 7;
+            const uint32_t level = ((2 * rot8 + slot8) * 4) / 22;
             if (level == 0) __builtin_amdgcn_s_setprio(0);
             else if (level == 1) __builtin_amdgcn_s_setprio(1);
             else if (level == 2) __builtin_amdgcn_s_setprio(2);

@@ -1,5 +1,5 @@
 #!/bin/bash
-# DELTA fast kernel variants: parity tests on each, then the bench line and the width sweep
+# Builds of the library side by side (build_exp/libpqd_NAME.so, tools/build_variant.sh): the DELTA parity tests on each, then the bench line twice, the width sweep (PQD_VPT_SWEEP=1) and the wide table (PQD_VPT_WIDE=1)
 set -e
 O=gpurun_out/vpt; mkdir -p $O
 for v in "$@"; do
