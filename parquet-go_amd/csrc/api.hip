@@ -112,6 +112,9 @@ constexpr size_t SIDE_BY_SIDE_MAX_ITEMS = 1024;     // batches up to this size f
 // Level pages of at most this many steps of RLE_TILE values are decoded by a workgroup each (one workgroup writes
 // about a kilobyte per 0.2 us: beyond, the tiles of the index + expand pair, spread over the chip, are quicker)
 constexpr uint64_t RLE_PAGE_MAX_STEPS = 128;
+// ... and longer ones whose bytes are few (long repeated runs: eight windows of the page kernel at most); what is slow
+// about a long page there is its expansion by one compute unit, and a batch of few pages shares that out
+constexpr uint64_t RLE_PAGE_MAX_BYTES = 32768;
 constexpr int RLE_GRIDS = 7;
 static_assert(RLE_GRIDS == sizeof(pqd_batch::rle_tiles) / sizeof(uint64_t), "one tile grid per RLE hybrid family");
 constexpr size_t RLE_CHUNKED_MAX_PAGES = 512;      // batches with more RLE pages than this index them one wavefront each
@@ -551,7 +554,7 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
     if (ctx->rle_page != 0) {
         for (DevPage& d : b->items)
             if (d.family == FAM_RLE_BYTES && d.kind == PQD_KIND_LEVELS && d.encoding == PQD_ENC_RLE && d.dst_stride <= 1 && !d.fused &&
-                (ctx->rle_page == 2 || rle_steps_of(d) <= RLE_PAGE_MAX_STEPS))
+                (ctx->rle_page == 2 || rle_steps_of(d) <= RLE_PAGE_MAX_STEPS || d.src_len <= RLE_PAGE_MAX_BYTES))
                 d.family = FAM_RLE_PAGE;
     }
 

@@ -1108,7 +1108,7 @@ __device__ __forceinline__ void expand_runs_bytes(const u32x4* tab, uint32_t nr,
 
 template <int NW = ET / 64>
 __device__ __forceinline__ void page_expand(const u32x4* tab, uint32_t nr, const uint32_t* win, int64_t base, const DevPage& pg, uint32_t G0,
-                                   uint32_t G1, uint32_t bw);
+                                   uint32_t G1, uint32_t bw, uint32_t share = 0, uint32_t shares = 1);
 
 // One-byte outputs (levels, booleans): a whole group of steps at once.  The runs that meet the
 // group are copied to LDS in one go, the packed bytes of all its bit-packed runs in another,
@@ -1296,6 +1296,13 @@ constexpr uint32_t PW_SLACK = 32;                 // LDS bytes behind the window
 #define PQD_PAGE_HOPS_LOG2 3
 #endif
 constexpr uint32_t PAGE_HOPS_LOG2 = PQD_PAGE_HOPS_LOG2;            // wide workgroups: the walk takes 2^3 headers per step (see page_chase_hops)
+#ifndef PQD_PAGE_SHARE_WGS
+#define PQD_PAGE_SHARE_WGS 256 // workgroups a batch's pages are shared out to at most
+#endif
+#ifndef PQD_PAGE_MAX_SHARES
+#define PQD_PAGE_MAX_SHARES 8
+#endif
+constexpr uint32_t PAGE_MAX_SHARES = PQD_PAGE_MAX_SHARES; // workgroups that may share one page's expansion
 constexpr uint64_t PAGE_RETRY = 0x5041474552455452ull; // DevResult::aux of a page rle_page_kernel left to the retry kernel
 static_assert(PW_WIN % ET == 0, "a whole number of positions per thread");
 
@@ -1403,8 +1410,10 @@ constexpr uint32_t PAGE_FEW_RUNS = 8; // up to so many runs behind the first tha
 
 template <int NW>
 __device__ __forceinline__ void page_expand(const u32x4* tab, uint32_t nr, const uint32_t* win, int64_t base, const DevPage& pg, uint32_t G0,
-                                   uint32_t G1, uint32_t bw) {
-    const uint32_t lane = threadIdx.x & 63, wave = NW == 1 ? 0u : pw_uniform(threadIdx.x >> 6); // NW wavefronts share the pieces
+                                   uint32_t G1, uint32_t bw, uint32_t share, uint32_t shares) {
+    // the NW wavefronts of `shares` workgroups share the pieces, 64 at a time in turn
+    const uint32_t lane = threadIdx.x & 63, wave = (NW == 1 ? 0u : pw_uniform(threadIdx.x >> 6)) + share * NW;
+    const uint32_t waves = NW * shares;
     gptr<uint8_t> dst = as_global(pg.dst);
     const uint32_t a = (uint32_t)((uintptr_t)pg.dst & 15); // piece c holds the values [16 c - a, 16 c - a + 16)
     for (uint32_t rb = 0; rb < nr; rb += 64) {
@@ -1416,7 +1425,7 @@ __device__ __forceinline__ void page_expand(const u32x4* tab, uint32_t nr, const
         const uint32_t B1 = last_end < G1 ? last_end : G1; // this stretch of runs holds [B0, B1)
         if (B1 <= B0) break;
         const uint32_t c_lo = (B0 + a) >> 4, c_hi = (B1 + a + 15) >> 4;
-        for (uint32_t c0 = c_lo + wave * 64; c0 < c_hi; c0 += NW * 64) {
+        for (uint32_t c0 = c_lo + wave * 64; c0 < c_hi; c0 += waves * 64) {
             const uint32_t c1 = c0 + 64 < c_hi ? c0 + 64 : c_hi;
             const uint32_t q_lo = c0 * 16 > B0 + a ? c0 * 16 - a : B0; // first value of these pieces inside the stretch
             const unsigned long long le = __ballot(mine.x <= q_lo);
@@ -1578,6 +1587,11 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T >= 256 ? 8 
     const DevPage& pg = pages[item];
     DevResult* res = &results[item];
     const uint32_t tid = threadIdx.x, wave = pw_uniform(tid >> 6), lane = tid & 63;
+    // gridDim.y workgroups to a page when the batch has few pages: each goes through the page's windows on its own (the
+    // walk is the same work done several times over, on compute units that would stand idle) and expands every
+    // gridDim.y-th stretch of the values -- a single compute unit writes a page of a million levels at 20 GB/s, whatever
+    // else the chip does.  The first of them reports.
+    const uint32_t share = blockIdx.y, shares = gridDim.y;
     // (everything the kernel wants of the descriptor is asked for at once, with no branch in between: a test per field
     // would be half a dozen trips to memory one after the other before the first byte of the page is on its way)
     const uint32_t bw = (uint32_t)pg.bit_width;
@@ -1732,14 +1746,15 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T >= 256 ? 8 
             if (state == 2) break;
             // ---- D: the values ----
             const uint32_t G1 = (uint32_t)G1_64;
-            if (G0 < limit && G1 > G0) page_expand<T / 64>(sh.tab, nr, sh.win, (int64_t)w_lo - (int64_t)mis, pg, G0, G1 < limit ? G1 : limit, bw);
+            if (G0 < limit && G1 > G0)
+                page_expand<T / 64>(sh.tab, nr, sh.win, (int64_t)w_lo - (int64_t)mis, pg, G0, G1 < limit ? G1 : limit, bw, share, shares);
             if (state == 1) break;
             pw_barrier(); // the window and the table are rewritten
             PQD_TICK(t_exp)
         }
         PQD_TICK(t_exp)
         if (state == 1) {
-            if (tid == 0) {
+            if (tid == 0 && share == 0) {
                 const uint64_t total = sh.total;
                 const uint64_t n_out = pg.num_values >= 0 && (uint64_t)pg.num_values < total ? (uint64_t)pg.num_values : total;
                 const bool too_small = n_out > pg.dst_cap;
@@ -1768,7 +1783,7 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(T >= 256 ? 8 
     }
     // ---- everything else is left to rle_page_retry_kernel: the page is marked, and so is the launch (launch numbers
     // only grow, so the word needs no clearing between launches: the retry kernel compares it with its own) ----
-    if (tid == 0) {
+    if (tid == 0 && share == 0) {
         res->aux = PAGE_RETRY;
         atomicMax(retry_word, launch);
     }
@@ -2803,8 +2818,10 @@ void launch_rle_pages(const DevPage* pages, DevResult* results, const uint32_t* 
     // (`threads`: 0, or the size a test or a measurement asks for)
     const uint32_t n_big = n_items - n_small;
     const uint32_t t = threads ? threads : n_big <= 512 ? 1024u : 256u;
+    // ... and when even wide workgroups leave compute units idle (two of them fit one), several share a page's expansion
+    const uint32_t shares = n_big > 0 ? std::min<uint32_t>(PAGE_MAX_SHARES, std::max<uint32_t>(1, PQD_PAGE_SHARE_WGS / n_big)) : 1;
     if (n_big > 0 && t == 1024)
-        hipLaunchKernelGGL(rle_page_kernel<1024>, dim3(n_big), dim3(1024), 0, stream, pages, results, items + n_small, retry_word, launch);
+        hipLaunchKernelGGL(rle_page_kernel<1024>, dim3(n_big, shares), dim3(1024), 0, stream, pages, results, items + n_small, retry_word, launch);
     else if (n_big > 0)
         hipLaunchKernelGGL(rle_page_kernel<256>, dim3(n_big), dim3(256), 0, stream, pages, results, items + n_small, retry_word, launch);
     hipLaunchKernelGGL(rle_page_retry_kernel, dim3(n_items < 256 ? n_items : 256), dim3(ET), 0, stream, pages, results, items, n_items, retry_word, launch);

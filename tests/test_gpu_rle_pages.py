@@ -217,3 +217,49 @@ def test_destinations_at_every_alignment(mode):
         assert res[k].status == 0 and res[k].out_values == want.size, (mode, k, res[k].status)
         assert np.array_equal(raw[a: a + want.size], want), (mode, k)
         assert (raw[:a] == 0xA5).all() and (raw[a + want.size:] == 0xA5).all(), (mode, k)
+
+
+def test_long_pages_of_few_bytes_shared_by_several_workgroups():
+    """Pages of a million levels and more in long runs (a few kilobytes each) in a batch of few pages: the page kernel
+    takes them whatever their length, and several workgroups share a page's expansion.  Whole pages, a page cut to
+    num_values, a destination that is too small, a damaged page (the retry kernel's), every destination alignment of
+    the first few."""
+    from tests.gpu_util import ctx
+    P = pkg()
+    from parquet_go_amd.runtime import decode_pages
+    rng = np.random.default_rng(1203)
+    cases = []
+    for k, (bw, n, short, long_) in enumerate(((1, 1 << 20, 6, 6000), (3, 1_500_000, 9, 4000), (2, 1_048_577, 30, 9000), (1, 3 << 20, 500, 20000),
+                                              (8, 700_001, 8, 5000))):
+        v = _runs_of(rng, n, 1 << bw, short, long_).astype(np.uint8)
+        enc = O.rle_encode_levels(v, bw) if k % 2 == 0 else O.rle_encode_levels_mr(v, bw)
+        assert len(enc) <= 32768 or bw == 8, (k, len(enc))
+        cases.append((f"long-bw{bw}", bw, enc, -1, n + 64))
+    bw, enc = cases[0][1], cases[0][2]
+    cases.append(("cut-to-num-values", bw, enc, 777_777, 800_000))
+    cases.append(("destination-too-small", bw, enc, -1, 500_000))
+    broken = bytearray(cases[1][2])
+    broken[len(broken) // 2] ^= 0xff
+    cases.append(("damaged", cases[1][1], bytes(broken), -1, 1_600_000))
+    specs = []
+    for k, (label, bw, enc, nv, cap) in enumerate(cases):
+        kw = dict(bit_width=bw, misalign=k % 16)
+        if nv >= 0:
+            kw["num_values"] = nv
+        if cap is not None:
+            kw["dst_cap"] = cap
+        specs.append(spec(P.ENC.RLE, P.KIND.LEVELS, enc, **kw))
+    outs = decode_pages(ctx(), specs, grow=False)
+    for (label, bw, enc, nv, cap), out in zip(cases, outs):
+        want = O.rle_decode_levels(enc, bw)
+        if want.status != 0:
+            assert_same(out, want, np.uint8, label, values=False)
+            continue
+        full = want.values
+        n = full.size if nv < 0 else min(nv, full.size)
+        if cap is not None and n > cap:
+            assert out.status == P.STATUS.DST_TOO_SMALL and out.arg == n and out.out_values == cap, (label, out.status, out.arg, out.out_values)
+            n = cap
+        else:
+            assert out.status == 0 and out.out_values == n, (label, out.status, out.arg, out.out_values)
+        assert np.array_equal(out.data[:n], full[:n]), label
