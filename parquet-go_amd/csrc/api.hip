@@ -115,6 +115,7 @@ constexpr uint64_t RLE_PAGE_MAX_STEPS = 128;
 // ... and longer ones whose bytes are few (long repeated runs: eight windows of the page kernel at most); what is slow
 // about a long page there is its expansion by one compute unit, and a batch of few pages shares that out
 constexpr uint64_t RLE_PAGE_MAX_BYTES = 32768;
+constexpr uint64_t RLE_PAGE_MAX_STEPS_FEW_BYTES = 1024; // (two million levels: a hundred million nulls in one run are the tiles')
 constexpr int RLE_GRIDS = 7;
 static_assert(RLE_GRIDS == sizeof(pqd_batch::rle_tiles) / sizeof(uint64_t), "one tile grid per RLE hybrid family");
 constexpr size_t RLE_CHUNKED_MAX_PAGES = 512;      // batches with more RLE pages than this index them one wavefront each
@@ -554,7 +555,8 @@ int pqd::batch_create_ws(pqd_ctx* ctx, const pqd_page* pages, uint64_t n_pages, 
     if (ctx->rle_page != 0) {
         for (DevPage& d : b->items)
             if (d.family == FAM_RLE_BYTES && d.kind == PQD_KIND_LEVELS && d.encoding == PQD_ENC_RLE && d.dst_stride <= 1 && !d.fused &&
-                (ctx->rle_page == 2 || rle_steps_of(d) <= RLE_PAGE_MAX_STEPS || d.src_len <= RLE_PAGE_MAX_BYTES))
+                (ctx->rle_page == 2 || rle_steps_of(d) <= RLE_PAGE_MAX_STEPS ||
+                 (d.src_len <= RLE_PAGE_MAX_BYTES && rle_steps_of(d) <= RLE_PAGE_MAX_STEPS_FEW_BYTES)))
                 d.family = FAM_RLE_PAGE;
     }
 
